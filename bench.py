@@ -1,0 +1,178 @@
+"""Throughput benchmark of the MossFormer2_SS_8K separation forward on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--seconds 4]
+
+One step = one forward pass over a batch of synthetic 8 kHz two-speaker
+mixtures already resident in HBM (the configuration the headline metric is
+quoted on: batch 16 of 4-second mixtures, fp32).  With N > 1 every rank (one
+process per GPU, launched by torch.distributed.run) separates its own batch --
+utterances are independent, so the path shards with no data-path collective;
+the only exchange is the gather of the separated waveforms and SI-SDR sums,
+done over RCCL after the timed region's compute and included in it.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def dominant_kernel_probe(model, B, T, reps=20):
+    """Average launch duration of the dominant kernel -- the fused pointwise
+    half of a TCN block, gemm_kernel<ProjNT<0,5>>: [B*S, 512] x two 512x512
+    weights with the gate / GroupNorm / residual epilogue; 8 launches per layer
+    x 24 layers = 53 % of the forward's FLOPs -- timed live with HIP events on
+    the stream it is launched on, through the C ABI, at the benchmark shape."""
+    from speech_separation_amd import _lib
+    lib = _lib.load()
+    pk = model.packed()
+    dev = pk.device
+    S = lib.msf2_num_frames(T)
+    C = model.cfg.dim
+    h = torch.randn(B, S, C, device=dev)
+    t = torch.randn(B, S, C, device=dev)
+    ho = torch.empty_like(h)
+    bstat = torch.tensor([[0.1, 1.3]] * B, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    tw = pk.layers[0].tcn[0]
+
+    def run():
+        _lib.check(lib.msf2_tcn_pointwise(h.data_ptr(), t.data_ptr(), bstat.data_ptr(), tw, ho.data_ptr(),
+                                          B, S, C, pk.c_cfg.precision, stream.cuda_stream))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * B * S * 2 * C * C          # two [M,C]x[C,C] products per launch
+    return ms, flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from speech_separation_amd.config import FULL_8K as cfg
+    from speech_separation_amd.model import MossFormerHIP
+    from speech_separation_amd.synth import make_state_dict, synth_batch, synth_mixture, permute_si_sdr
+
+    B, T = a.batch, int(round(a.seconds * 8000))
+    sd = make_state_dict(cfg, 0)
+    model = MossFormerHIP(cfg, compute_device=dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    x = torch.from_numpy(synth_batch(B, T, seed0=rank * B)).to(dev)
+
+    gathered = [torch.empty((cfg.num_spks, B, T), device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        out = torch.stack(model(x), 0)
+        if world > 1:
+            dist.all_gather(gathered, out)
+        return out
+
+    for _ in range(a.warmup):
+        out = step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    audio_s = world * B * T / 8000.0 * a.steps
+    res = {
+        "metric": "audio-sec separated/sec (8 kHz)",
+        "value": audio_s / dt,
+        "unit": "audio-s/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {a.seconds:g} s Libri2Mix-min-shaped 8 kHz mixtures, "
+                               "fp32, random-init weights (seeded recipe)",
+                   "batch_per_gpu": B, "samples": T, "layers": cfg.num_layers, "dim": cfg.dim,
+                   "parallelism": f"utterance-sharded x{world}"},
+        "model_tflops_per_s": world * B * cfg.flops(T) * a.steps / dt / 1e12,
+    }
+
+    if rank == 0:
+        ms, flops = dominant_kernel_probe(model, B, T)
+        peak = 157.3
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
+                           "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
+                           "launch_ms": ms}
+        if not a.no_cpu_baseline and world == 1:
+            from oracle import cpu_ref           # the CPU port that is timed, never the product path
+            cores = min(os.cpu_count() or 1, 16)
+            torch.set_num_threads(cores)
+            W = cpu_ref.to_torch(sd)
+            xs = torch.from_numpy(synth_batch(1, T, seed0=0))
+            with torch.no_grad():
+                c0 = time.perf_counter()
+                ref = cpu_ref.forward(W, xs, cfg)
+                cdt = time.perf_counter() - c0
+            got = torch.stack(model(xs.to(dev)), 0).cpu().numpy()
+            refn = torch.stack(ref, 0).numpy()
+            mix, s1, s2 = synth_mixture(T, 0)
+            sdr_cpu = permute_si_sdr(refn[0, 0], refn[1, 0], s1, s2)
+            sdr_gpu = permute_si_sdr(got[0, 0], got[1, 0], s1, s2)
+            res["cpu_baseline"] = {"value": (T / 8000.0) / cdt, "unit": "audio-s/s", "cores": cores, "kind": "port",
+                                   "sample": f"one {a.seconds:g} s mixture (batch 1), fp32, one pass, oracle/cpu_ref.py"}
+            res["max_abs_err_vs_cpu"] = float(np.abs(got - refn).max())
+            res["si_sdr_delta_db"] = sdr_gpu - sdr_cpu
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

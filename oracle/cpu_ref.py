@@ -80,17 +80,12 @@ def rotary(t, freqs):
     return torch.cat((out, tp), dim=-1)
 
 
-def flash_layer(x, W, p, group=256):
-    """FLASH_ShareA_FFConvM.forward (reference: mossformer2_block.py:221-325)."""
-    B, S, D = x.shape
-    half = D // 2
-    shifted = torch.cat((F.pad(x[..., :half], (0, 0, 1, -1)), x[..., half:]), dim=-1)
-    hu = ffconvm(shifted, W, f"{p}.to_hidden")
-    v, u = hu.chunk(2, dim=-1)
-    qk = ffconvm(shifted, W, f"{p}.to_qk")
-    gam, bet = W[f"{p}.qk_offset_scale.gamma"], W[f"{p}.qk_offset_scale.beta"]
+def attention_core(v, u, qk, gam, bet, freqs, group=256):
+    """OffsetScale + rotary + grouped quadratic attention + global linear
+    attention + output gating (reference: mossformer2_block.py:255-258, :262-325).
+    v, u: [B, S, E]; qk: [B, S, 128]; returns o = (att_u * v) * sigmoid(att_v * u)."""
+    B, S, _ = v.shape
     heads = [qk * gam[h] + bet[h] for h in range(4)]
-    freqs = W[f"{p}.rotary_pos_emb.freqs"]
     quad_q, lin_q, quad_k, lin_k = [rotary(t, freqs) for t in heads]
     pad = (group - S % group) % group
     if pad:
@@ -114,7 +109,22 @@ def flash_layer(x, W, p, group=256):
     lin_u = torch.einsum("bgnd,bde->bgne", lq, lin_ku)
     att_v = (quad_v + lin_v).reshape(B, G * group, -1)[:, :S]
     att_u = (quad_u + lin_u).reshape(B, G * group, -1)[:, :S]
-    out = (att_u * v) * torch.sigmoid(att_v * u)
+    return (att_u * v) * torch.sigmoid(att_v * u)
+
+
+def token_shift(x):
+    """reference: mossformer2_block.py:245-248"""
+    half = x.shape[-1] // 2
+    return torch.cat((F.pad(x[..., :half], (0, 0, 1, -1)), x[..., half:]), dim=-1)
+
+
+def flash_layer(x, W, p, group=256):
+    """FLASH_ShareA_FFConvM.forward (reference: mossformer2_block.py:221-260)."""
+    shifted = token_shift(x)
+    v, u = ffconvm(shifted, W, f"{p}.to_hidden").chunk(2, dim=-1)
+    qk = ffconvm(shifted, W, f"{p}.to_qk")
+    out = attention_core(v, u, qk, W[f"{p}.qk_offset_scale.gamma"], W[f"{p}.qk_offset_scale.beta"],
+                         W[f"{p}.rotary_pos_emb.freqs"], group)
     return x + ffconvm(out, W, f"{p}.to_out")
 
 

@@ -1,0 +1,426 @@
+// libmsf2: C-ABI entry points and the host-side launch sequence of the
+// MossFormer2_SS forward pass.  All work is enqueued on the caller's stream;
+// nothing here allocates, synchronises or keeps mutable global state.
+#include "msf2_common.h"
+#include "msf2_gemm.h"
+#include "msf2_ops.h"
+
+namespace msf2 {
+
+thread_local int g_last_hip_error = 0;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool dim_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+
+constexpr int ENC_TS = 32;    // frames per block in the encoder / TCN stage A kernels
+constexpr int TCN_TS = 32;
+
+struct Ctx {
+    hipStream_t st;
+    int B, S, T;
+    long M;
+};
+
+// ---- projection launcher ----------------------------------------------------
+template <int AMODE, int EPI>
+static void launch_proj(const Ctx& c, const ProjArgs& a) {
+    typedef ProjNT<AMODE, EPI> P;
+    dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
+    hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), 0, c.st, a);
+}
+
+static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N, int S, float* out, int ldo) {
+    ProjArgs a = {};
+    a.A = A; a.lda = lda; a.W = W; a.K = K; a.N = N; a.S = S; a.out = out; a.ldo = ldo;
+    return a;
+}
+
+static void launch_stats_finalize(const Ctx& c, const float* part, int nblk, long count_per_b, float eps, float* stats) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(c.B), dim3(64), 0, c.st, part, nblk, (double)count_per_b, eps, stats);
+}
+
+template <int MODE>
+static void launch_rowstat(const Ctx& c, const float* x, int ldx, float* out, int C, int shift, float eps) {
+    hipLaunchKernelGGL(rowstat_kernel<MODE>, dim3(cdiv(c.M, 4)), dim3(256), 0, c.st, x, ldx, out, c.M, c.S, C, shift, eps);
+}
+
+static void launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate) {
+    dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
+    hipLaunchKernelGGL(dwconv17_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate);
+}
+
+// ---- FLASH attention core ---------------------------------------------------
+struct AttnWs {
+    float *q4, *P, *part, *kv;
+    int nsplit, chunk, G;
+};
+static int attn_nsplit(int B, int S) {
+    int n = cdiv(1024, 16L * B);
+    const int maxn = cdiv(S, 256);
+    if (n > maxn) n = maxn;
+    if (n < 1) n = 1;
+    return n;
+}
+static AttnWs attn_ws(Arena& ar, int B, int S, int E) {
+    AttnWs w;
+    w.G = cdiv(S, MSF2_GROUP);
+    w.nsplit = attn_nsplit(B, S);
+    w.chunk = cdiv(cdiv(S, w.nsplit), BK) * BK;
+    w.nsplit = cdiv(S, w.chunk);
+    w.q4 = ar.take<float>(4L * B * S * MSF2_QK_DIM);
+    w.P = ar.take<float>((long)B * w.G * MSF2_GROUP * MSF2_GROUP);
+    w.part = ar.take<float>((long)B * w.nsplit * MSF2_QK_DIM * 2 * E);
+    w.kv = ar.take<float>((long)B * MSF2_QK_DIM * 2 * E);
+    return w;
+}
+static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ldhu, const float* gamma,
+                          const float* beta, const float* freqs, float* o, int E) {
+    const long M = c.M;
+    hipLaunchKernelGGL(qk_prep_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, hu + 2 * E, ldhu, gamma, beta, freqs, w.q4, M, c.S);
+    const float* quad_q = w.q4;
+    const float* lin_q = w.q4 + 1 * M * MSF2_QK_DIM;
+    const float* quad_k = w.q4 + 2 * M * MSF2_QK_DIM;
+    const float* lin_k = w.q4 + 3 * M * MSF2_QK_DIM;
+    {
+        LinKVArgs a = {lin_k, hu, ldhu, w.part, c.S, 2 * E, w.chunk};
+        hipLaunchKernelGGL(gemm_kernel<LinKV>, dim3(cdiv(2 * E, BN), w.nsplit, c.B), dim3(256), 0, c.st, a);
+        const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
+        hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
+    }
+    {
+        SimArgs a = {quad_q, quad_k, w.P, c.S, w.G};
+        hipLaunchKernelGGL(gemm_kernel<AttnSim>, dim3(2, 2, c.B * w.G), dim3(256), 0, c.st, a);
+    }
+    {
+        AttnOutArgs a = {w.P, lin_q, hu, ldhu, w.kv, o, c.S, w.G, E};
+        hipLaunchKernelGGL(gemm_kernel<AttnOut>, dim3(E / (BN / 2), 2, c.B * w.G), dim3(256), 0, c.st, a);
+    }
+}
+
+// ---- gated TCN block ----------------------------------------------------------
+struct TcnWs {
+    float *rowstat, *g, *h0, *h1, *t, *part, *bstat;
+    int nblk;
+};
+static TcnWs tcn_ws(Arena& ar, int B, int S, int C) {
+    TcnWs w;
+    const long M = (long)B * S;
+    w.nblk = cdiv(S, TCN_TS);
+    w.rowstat = ar.take<float>(2 * M);
+    w.g = ar.take<float>(M * C);
+    w.h0 = ar.take<float>(M * C);
+    w.h1 = ar.take<float>(M * C);
+    w.t = ar.take<float>(M * C);
+    w.part = ar.take<float>(2L * B * w.nblk);
+    w.bstat = ar.take<float>(2L * B);
+    return w;
+}
+static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
+    // g = sigmoid(x Wgg^T + b)
+    {
+        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
+        a.bias = lw.b_gg; a.act = 2;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    // h = LayerNorm(x) Win^T + b   (normalisation folded into the epilogue)
+    launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
+    {
+        ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, w.h0, C);
+        a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in;
+        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    }
+    float* h = w.h0;
+    float* hn = w.h1;
+    for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
+        const msf2_tcn_weights& tw = lw.tcn[j];
+        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part,
+                           c.S, C, 1 << j, TCN_TS);
+        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
+        ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
+        a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
+        a.bstat = w.bstat; a.res = h; a.ldr = C;
+        launch_proj<A_PLAIN, EPI_TCN>(c, a);
+        float* tmp = h; h = hn; hn = tmp;
+    }
+    // x += (g * h) Wpo^T + b
+    {
+        ProjArgs a = proj_args(w.g, C, lw.w_po, C, C, c.S, x, C);
+        a.A2 = h; a.bias = lw.b_po; a.res = x; a.ldr = C;
+        launch_proj<A_MUL, EPI_BIAS_RES>(c, a);
+    }
+}
+
+// ---- decoder ----------------------------------------------------------------
+static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, float* fv, float* est, int C) {
+    int grid = cdiv(c.M, 4);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(decoder_frames_kernel, dim3(grid), dim3(256), (size_t)C * 20 * sizeof(float), c.st, sep, dec_w, fv, c.M, C);
+    const long n = (long)c.B * c.T;
+    hipLaunchKernelGGL(decoder_ola_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c.st, fv, est, c.B, c.S, c.T);
+}
+
+// ---- whole forward ----------------------------------------------------------
+struct FwdWs {
+    float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv;
+    AttnWs at;
+    TcnWs tc;
+    int nblk_enc, nblk_ln;
+};
+static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
+    FwdWs w;
+    const int C = cfg.dim, E = 2 * C, NH = 4 * C + MSF2_QK_DIM;
+    const long M = (long)B * S;
+    w.nblk_enc = cdiv(S, ENC_TS);
+    w.nblk_ln = cdiv(S, 32);
+    w.enc = ar.take<float>(M * C);
+    w.skip = ar.take<float>(M * C);
+    w.x = ar.take<float>(M * C);
+    w.hu_pre = ar.take<float>(M * NH);   // reused by the mask head: z [M, 2C] and masked features [2][M, C]
+    w.hu = ar.take<float>(M * NH);       // reused by the mask head: gated features [2][M, C]
+    w.o = ar.take<float>(M * E);
+    w.po = ar.take<float>(M * C);
+    w.rowstat = ar.take<float>(2 * M);
+    const int nb = w.nblk_enc > w.nblk_ln ? w.nblk_enc : w.nblk_ln;
+    w.part = ar.take<float>(2L * B * nb);
+    w.bstat = ar.take<float>(2L * B);
+    w.pe = ar.take<float>((long)S * C);
+    w.fv = ar.take<float>(M * 16);
+    w.at = attn_ws(ar, B, S, E);
+    w.tc = tcn_ws(ar, B, S, C);
+    return w;
+}
+
+static int check_cfg(const msf2_config* cfg) {
+    if (!cfg) return MSF2_ERR_ARG;
+    if (!dim_ok(cfg->dim) || cfg->num_layers < 0 || cfg->enc_kernel != 16 || cfg->num_spks != 2) return MSF2_ERR_ARG;
+    if (cfg->precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    return MSF2_OK;
+}
+
+static void copy_tap(const Ctx& c, float* dst, const float* src, long n) {
+    if (dst) hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, c.st);
+}
+
+}  // namespace msf2
+
+using namespace msf2;
+
+extern "C" {
+
+const char* msf2_strerror(int code) {
+    switch (code) {
+        case MSF2_OK: return "ok";
+        case MSF2_ERR_ARG: return "invalid argument (null pointer, unsupported shape or configuration)";
+        case MSF2_ERR_WORKSPACE: return "workspace too small";
+        case MSF2_ERR_LAUNCH: return "HIP kernel launch failed";
+        default: return "unknown error";
+    }
+}
+int msf2_last_hip_error(void) { return g_last_hip_error; }
+int msf2_version(void) { return 1; }
+int msf2_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(msf2_config);
+        case 1: return (int)sizeof(msf2_tcn_weights);
+        case 2: return (int)sizeof(msf2_layer_weights);
+        case 3: return (int)sizeof(msf2_weights);
+        case 4: return (int)sizeof(msf2_taps);
+        default: return -1;
+    }
+}
+int msf2_num_frames(int T) { return T < 16 ? 0 : (T - 16) / 8 + 1; }
+
+size_t msf2_workspace_bytes(const msf2_config* cfg, int B, int T) {
+    if (check_cfg(cfg) != MSF2_OK || B < 1 || T < 16) return 0;
+    Arena ar(nullptr, 0);
+    fwd_ws(ar, *cfg, B, msf2_num_frames(T));
+    return ar.off;
+}
+
+int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mix, float* out, int B, int T,
+                 void* workspace, size_t workspace_bytes, const msf2_taps* taps, void* stream) {
+    int rc = check_cfg(cfg);
+    if (rc != MSF2_OK) return rc;
+    if (!wt || !mix || !out || !workspace || B < 1 || T < 16 || (cfg->num_layers > 0 && !wt->layers)) return MSF2_ERR_ARG;
+    const int C = cfg->dim, E = 2 * C, NH = 4 * C + MSF2_QK_DIM, S = msf2_num_frames(T);
+    Arena ar(workspace, workspace_bytes);
+    FwdWs w = fwd_ws(ar, *cfg, B, S);
+    if (!ar.ok()) return MSF2_ERR_WORKSPACE;
+    Ctx c = {(hipStream_t)stream, B, S, T, (long)B * S};
+    const long MC = c.M * C;
+    msf2_taps tp = {};
+    if (taps) tp = *taps;
+
+    // encoder + statistics for the mask net's GroupNorm(1, C, eps 1e-8)
+    hipLaunchKernelGGL(encoder_kernel, dim3(w.nblk_enc, B), dim3(256), 0, c.st, mix, wt->enc_w, w.enc, w.part, T, S, C, ENC_TS);
+    launch_stats_finalize(c, w.part, w.nblk_enc, (long)S * C, 1e-8f, w.bstat);
+    hipLaunchKernelGGL(posenc_kernel, dim3(cdiv((long)S * (C / 2), 256)), dim3(256), 0, c.st, wt->pe_inv_freq, wt->pe_scale, w.pe, S, C);
+    {   // x = skip = GroupNorm(enc) Wce^T + pos_enc
+        ProjArgs a = proj_args(w.enc, C, wt->w_ce, C, C, S, w.x, C);
+        a.out2 = w.skip; a.bstat = w.bstat; a.c1 = wt->c1_ce; a.c2 = wt->c2_ce; a.pe = w.pe;
+        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    }
+    copy_tap(c, tp.enc, w.enc, MC);
+    copy_tap(c, tp.x0, w.x, MC);
+
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        const msf2_layer_weights& lw = wt->layers[l];
+        // ---- FLASH_ShareA_FFConvM ----
+        launch_rowstat<0>(c, w.x, C, w.rowstat, C, 1, 0.f);
+        {   // [v | u | qk] = silu(ScaleNorm(shift(x)) W^T + b)
+            ProjArgs a = proj_args(w.x, C, lw.w_hq, C, NH, S, w.hu_pre, NH);
+            a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1;
+            launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
+        }
+        launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
+        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E);
+        launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
+        {   // to_out projection
+            ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);
+            a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1;
+            launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+        }
+        launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1);   // x += po + dwconv17(po)
+        if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
+        // ---- GatedTCNBlock ----
+        run_gated_tcn(c, w.tc, w.x, lw, C);
+        if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);
+    }
+
+    // final LayerNorm(eps 1e-6) -> GroupNorm(1, C, eps 1e-8) + skip -> PReLU
+    hipLaunchKernelGGL(final_ln_kernel, dim3(w.nblk_ln, B), dim3(256), 0, c.st, w.x, wt->fin_ln_w, wt->fin_ln_b, w.part, S, C, 1e-6f);
+    launch_stats_finalize(c, w.part, w.nblk_ln, (long)S * C, 1e-8f, w.bstat);
+    hipLaunchKernelGGL(final_gn_kernel, dim3(cdiv(MC / 4, 256)), dim3(256), 0, c.st, w.x, w.skip, w.bstat, wt->fin_gn_w,
+                       wt->fin_gn_b, wt->prelu_a, w.po, tp.mdl, c.M, S, C);
+
+    // mask head
+    float* z = w.hu_pre;                 // [M, 2C]
+    float* zz = w.hu;                    // [2][M, C]
+    float* sep = w.hu_pre + c.M * 2 * C; // [2][M, C]
+    {
+        ProjArgs a = proj_args(w.po, C, wt->w_co, C, 2 * C, S, z, 2 * C);
+        a.bias = wt->b_co; a.act = 0;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    for (int sp = 0; sp < 2; ++sp) {
+        {
+            ProjArgs a = proj_args(z + sp * C, 2 * C, wt->w_o, C, C, S, zz + sp * MC, C);
+            a.W2 = wt->w_og; a.bias = wt->b_o; a.bias2 = wt->b_og;
+            launch_proj<A_PLAIN, EPI_TANH_SIG>(c, a);
+        }
+        {
+            ProjArgs a = proj_args(zz + sp * MC, C, wt->w_cd, C, C, S, sep + sp * MC, C);
+            a.res = w.enc; a.ldr = C; a.out2 = sp == 0 ? tp.mask0 : tp.mask1;
+            launch_proj<A_PLAIN, EPI_RELU_MUL>(c, a);
+        }
+        run_decoder(c, sep + sp * MC, wt->dec_w, w.fv, out + (long)sp * B * T, C);
+    }
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// single operators
+// ---------------------------------------------------------------------------
+size_t msf2_stats_ws_bytes(int B, int S) { return align_up(2L * B * cdiv(S, ENC_TS) * sizeof(float)); }
+
+int msf2_encoder(const float* mix, const float* enc_w, float* enc, float* stats, float eps, int B, int T, int C,
+                 void* ws, size_t ws_bytes, void* stream) {
+    if (!mix || !enc_w || !enc || !stats || !ws || B < 1 || T < 16 || !dim_ok(C)) return MSF2_ERR_ARG;
+    const int S = msf2_num_frames(T);
+    if (ws_bytes < msf2_stats_ws_bytes(B, S)) return MSF2_ERR_WORKSPACE;
+    Ctx c = {(hipStream_t)stream, B, S, T, (long)B * S};
+    const int nblk = cdiv(S, ENC_TS);
+    hipLaunchKernelGGL(encoder_kernel, dim3(nblk, B), dim3(256), 0, c.st, mix, enc_w, enc, (float*)ws, T, S, C, ENC_TS);
+    launch_stats_finalize(c, (float*)ws, nblk, (long)S * C, eps, stats);
+    return check_launch();
+}
+
+int msf2_dwconv17(const float* x, int ldx, const float* dw, float* y, int ldy, int B, int S, int C, int accumulate,
+                  void* stream) {
+    if (!x || !dw || !y || B < 1 || S < 1 || C < 4 || (C & 3) || ldx < C || ldy < C || (ldx & 3) || (ldy & 3)) return MSF2_ERR_ARG;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    launch_dwconv17(c, x, ldx, dw, y, ldy, C, accumulate);
+    return check_launch();
+}
+
+size_t msf2_linear_ws_bytes(int B, int S) { return align_up((size_t)B * S * sizeof(float)); }
+
+int msf2_linear(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int B, int S, int K, int N,
+                int shift, int scale_norm, int act, int precision, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !W || !y || B < 1 || S < 1 || K < BK || (K % BK) || K > 1024 || N < 1 || ldx < K || ldy < N || (ldx & 3)) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32 || act < 0 || act > 2) return MSF2_ERR_ARG;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    ProjArgs a = proj_args(x, ldx, W, K, N, S, y, ldy);
+    a.bias = b; a.act = act;
+    if (scale_norm) {
+        if (!ws || ws_bytes < msf2_linear_ws_bytes(B, S)) return MSF2_ERR_WORKSPACE;
+        launch_rowstat<0>(c, x, ldx, (float*)ws, K, shift, 0.f);
+        a.rowstat = (float*)ws;
+    }
+    if (shift) launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
+    else launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    return check_launch();
+}
+
+size_t msf2_flash_attention_ws_bytes(int B, int S, int E) {
+    Arena ar(nullptr, 0);
+    attn_ws(ar, B, S, E);
+    return ar.off;
+}
+
+int msf2_flash_attention(const float* hu, int ldhu, const float* os_gamma, const float* os_beta, const float* rot_freqs,
+                         float* o, int B, int S, int E, int precision, void* ws, size_t ws_bytes, void* stream) {
+    if (!hu || !os_gamma || !os_beta || !rot_freqs || !o || !ws || B < 1 || S < 1 || E < 128 || (E % 64) ||
+        ldhu < 2 * E + MSF2_QK_DIM || (ldhu & 3))
+        return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    Arena ar(ws, ws_bytes);
+    AttnWs w = attn_ws(ar, B, S, E);
+    if (!ar.ok()) return MSF2_ERR_WORKSPACE;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    run_attention(c, w, hu, ldhu, os_gamma, os_beta, rot_freqs, o, E);
+    return check_launch();
+}
+
+size_t msf2_gated_tcn_ws_bytes(int B, int S, int C) {
+    Arena ar(nullptr, 0);
+    tcn_ws(ar, B, S, C);
+    return ar.off;
+}
+
+int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, int precision, void* ws, size_t ws_bytes,
+                   void* stream) {
+    if (!x || !lw || !ws || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    Arena ar(ws, ws_bytes);
+    TcnWs w = tcn_ws(ar, B, S, C);
+    if (!ar.ok()) return MSF2_ERR_WORKSPACE;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    run_gated_tcn(c, w, x, *lw, C);
+    return check_launch();
+}
+
+int msf2_tcn_pointwise(const float* h, const float* t, const float* bstat, const msf2_tcn_weights* tw, float* h_out,
+                       int B, int S, int C, int precision, void* stream) {
+    if (!h || !t || !bstat || !tw || !h_out || h == h_out || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    ProjArgs a = proj_args(h, C, tw->w_gate, C, C, S, h_out, C);
+    a.A2 = t; a.W2 = tw->w_pw; a.bias = tw->b_gate; a.c1 = tw->c1; a.c2 = tw->c2;
+    a.bstat = bstat; a.res = h; a.ldr = C;
+    launch_proj<A_PLAIN, EPI_TCN>(c, a);
+    return check_launch();
+}
+
+size_t msf2_decoder_ws_bytes(int B, int S) { return align_up((size_t)B * S * 16 * sizeof(float)); }
+
+int msf2_decoder(const float* sep, const float* dec_w, float* est, int B, int S, int C, int T, void* ws, size_t ws_bytes,
+                 void* stream) {
+    if (!sep || !dec_w || !est || !ws || B < 1 || S < 1 || T < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
+    if (ws_bytes < msf2_decoder_ws_bytes(B, S)) return MSF2_ERR_WORKSPACE;
+    Ctx c = {(hipStream_t)stream, B, S, T, (long)B * S};
+    run_decoder(c, sep, dec_w, (float*)ws, est, C);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Shared device helpers and launch plumbing for libmsf2 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/msf2.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace msf2 {
+
+extern thread_local int g_last_hip_error;
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return MSF2_ERR_LAUNCH;
+    }
+    return MSF2_OK;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace.
+struct Arena {
+    char* base;
+    size_t cap, off;
+    Arena(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+    template <class T> T* take(size_t n) {
+        size_t bytes = align_up(n * sizeof(T));
+        char* r = base ? base + off : nullptr;
+        off += bytes;
+        return (T*)r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread. `red` : >= 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace msf2

@@ -1,0 +1,387 @@
+// Bandwidth-bound kernels of the separation forward pass: every one streams
+// token-major [B, S, C] rows with the channel index on the lanes (float4 per
+// lane, 128-bit coalesced), reduces with wavefront shuffles, and folds the
+// statistics the next normalisation needs into the producer.
+#pragma once
+#include "msf2_common.h"
+
+namespace msf2 {
+
+// Mapping used by the per-frame kernels: a 256-thread block covers
+// nf = 256 / (C/4) frames at a time, thread = (frame offset fo, channel quad cq).
+// Requires C in {64, 128, 256, 512, 1024}.
+struct QuadMap {
+    int cq, fo, nf;
+    __device__ QuadMap(int C) {
+        const int q = C >> 2;
+        cq = threadIdx.x % q;
+        fo = threadIdx.x / q;
+        nf = 256 / q;
+    }
+};
+
+__device__ __forceinline__ void write_partial(float sum, float sq, float* part, float* red) {
+    // part -> two floats of this block
+    const float s = block_sum_256(sum, red);
+    const float q = block_sum_256(sq, red + 4);
+    if (threadIdx.x == 0) { part[0] = s; part[1] = q; }
+}
+
+// ---- encoder: relu(conv1d(k=16, stride 8)), token-major, + partial sums -----
+// grid (ceil(S/TS), B), block 256.  w: [16][C].  part: [B][gridDim.x][2]
+__global__ __launch_bounds__(256) void encoder_kernel(const float* __restrict__ mix, const float* __restrict__ w,
+                                                      float* __restrict__ enc, float* __restrict__ part,
+                                                      int T, int S, int C, int TS) {
+    __shared__ float red[8];
+    const QuadMap qm(C);
+    const int b = blockIdx.y, s0 = blockIdx.x * TS, s1 = min(s0 + TS, S);
+    float4 wq[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wq[k] = *reinterpret_cast<const float4*>(w + k * C + 4 * qm.cq);
+    float sum = 0.f, sq = 0.f;
+    for (int s = s0 + qm.fo; s < s1; s += qm.nf) {
+        const float* x = mix + (long)b * T + 8 * s;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float xv = x[k];
+            acc.x += wq[k].x * xv; acc.y += wq[k].y * xv; acc.z += wq[k].z * xv; acc.w += wq[k].w * xv;
+        }
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        *reinterpret_cast<float4*>(enc + ((long)b * S + s) * C + 4 * qm.cq) = acc;
+        sum += acc.x + acc.y + acc.z + acc.w;
+        sq += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+    }
+    write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
+}
+
+// ---- (mean, rstd) of one utterance from block partials ----------------------
+// grid B, block 64.  stats: [B][2]
+__global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restrict__ part, int nblk, double count,
+                                                            float eps, float* __restrict__ stats) {
+    const int b = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+        s += (double)part[((long)b * nblk + i) * 2];
+        q += (double)part[((long)b * nblk + i) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * b] = (float)mean;
+        stats[2 * b + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- ScaledSinuEmbedding table: pe[s][j] = sin(s f_j) scale | cos(s f_j) scale
+__global__ void posenc_kernel(const float* __restrict__ inv_freq, float scale, float* __restrict__ pe, int S, int C) {
+    const int half = C >> 1;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)S * half) return;
+    const int s = (int)(i / half), j = (int)(i % half);
+    const float ang = (float)s * inv_freq[j];
+    pe[(long)s * C + j] = sinf(ang) * scale;
+    pe[(long)s * C + half + j] = cosf(ang) * scale;
+}
+
+// ---- per-row statistics, one wave per row -----------------------------------
+// MODE 0: ScaleNorm inverse norm 1 / max(|x| / sqrt(C), 1e-5) of the
+//         (optionally token-shifted) row -> out[m]
+// MODE 1: LayerNorm (mean, rstd) -> out[2m], out[2m+1]
+// grid ceil(M/4), block 256.  C <= 1024.
+template <int MODE>
+__global__ __launch_bounds__(256) void rowstat_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
+                                                      long M, int S, int C, int shift, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nq = C >> 2;
+    float4 v[4];
+    float sum = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) {
+            long row = m;
+            bool zero = false;
+            if (MODE == 0 && shift && 4 * q < (C >> 1)) {
+                if (m % S == 0) zero = true;
+                row = m - 1;
+            }
+            if (!zero) v[i] = *reinterpret_cast<const float4*>(x + row * ldx + 4 * q);
+        }
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    if (MODE == 0) {
+        ss = wave_sum(ss);
+        if (lane == 0) out[m] = 1.0f / fmaxf(sqrtf(ss) * rsqrtf((float)C), 1e-5f);
+    } else {
+        const float mean = wave_sum(sum) / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (lane + 64 * i < nq) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                d2 += a * a + b * b + c * c + d * d;
+            }
+        }
+        d2 = wave_sum(d2);
+        if (lane == 0) {
+            out[2 * m] = mean;
+            out[2 * m + 1] = rsqrtf(d2 / (float)C + eps);
+        }
+    }
+}
+
+// ---- ConvModule: y = x + dwconv17(x) along time (zero padded) ---------------
+// grid (ceil(C/4 / 128), ceil(S/TS), B), block 128, TS = 16.  dw: [17][C]
+constexpr int DW_TS = 16;
+__global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dw,
+                                                       float* __restrict__ y, int ldy, int S, int C, int accumulate) {
+    const int cq = blockIdx.x * 128 + threadIdx.x;
+    if (cq >= (C >> 2)) return;
+    const int b = blockIdx.z, s0 = blockIdx.y * DW_TS;
+    float4 w[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) w[k] = *reinterpret_cast<const float4*>(dw + k * C + 4 * cq);
+    float4 acc[DW_TS];
+#pragma unroll
+    for (int o = 0; o < DW_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb = x + (long)b * S * ldx + 4 * cq;
+#pragma unroll
+    for (int r = -8; r < DW_TS + 8; ++r) {
+        const int s = s0 + r;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s >= 0 && s < S) xv = *reinterpret_cast<const float4*>(xb + (long)s * ldx);
+#pragma unroll
+        for (int o = 0; o < DW_TS; ++o) {
+            const int k = r - o + 8;
+            if (k >= 0 && k < 17) {
+                acc[o].x += w[k].x * xv.x; acc[o].y += w[k].y * xv.y;
+                acc[o].z += w[k].z * xv.z; acc[o].w += w[k].w * xv.w;
+            }
+            if (r == o) { acc[o].x += xv.x; acc[o].y += xv.y; acc[o].z += xv.z; acc[o].w += xv.w; }
+        }
+    }
+    float* yb = y + (long)b * S * ldy + 4 * cq;
+#pragma unroll
+    for (int o = 0; o < DW_TS; ++o) {
+        const int s = s0 + o;
+        if (s < S) {
+            float4 v = acc[o];
+            if (accumulate) {
+                const float4 p = *reinterpret_cast<const float4*>(yb + (long)s * ldy);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            *reinterpret_cast<float4*>(yb + (long)s * ldy) = v;
+        }
+    }
+}
+
+// ---- OffsetScale + rotary -> quad_q/256, lin_q, quad_k, lin_k ----------------
+// qk: [M] rows, row stride ld (already offset to the qk columns).  q4: [4][M][128].
+// grid ceil(M/4), block 256 (64 lanes = 64 feature pairs of one row)
+__global__ __launch_bounds__(256) void qk_prep_kernel(const float* __restrict__ qk, int ld,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ freqs, float* __restrict__ q4,
+                                                      long M, int S) {
+    const int p = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float2 x = *reinterpret_cast<const float2*>(qk + m * ld + 2 * p);
+    float c = 1.f, sn = 0.f;
+    if (p < 16) {
+        const float ang = (float)(m % S) * freqs[p];
+        c = cosf(ang);
+        sn = sinf(ang);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float2 g = *reinterpret_cast<const float2*>(gamma + h * MSF2_QK_DIM + 2 * p);
+        const float2 bb = *reinterpret_cast<const float2*>(beta + h * MSF2_QK_DIM + 2 * p);
+        const float y0 = x.x * g.x + bb.x, y1 = x.y * g.y + bb.y;
+        float2 o;
+        o.x = y0 * c - y1 * sn;
+        o.y = y1 * c + y0 * sn;
+        if (h == 0) { o.x *= (1.0f / MSF2_GROUP); o.y *= (1.0f / MSF2_GROUP); }
+        *reinterpret_cast<float2*>(q4 + ((long)h * M + m) * MSF2_QK_DIM + 2 * p) = o;
+    }
+}
+
+// ---- kv[b][d][e] = sum_sp part[b][sp][d][e] / S ------------------------------
+__global__ void kv_finalize_kernel(const float* __restrict__ part, float* __restrict__ kv, int nsplit, long per_b, int S, long total) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= total) return;
+    const long b = i / per_b, r = i % per_b;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (b * nsplit + sp) * per_b + r);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float n = (float)S;
+    acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+    *reinterpret_cast<float4*>(kv + i) = acc;
+}
+
+// ---- TCN stage A: t = silu(dwconv3_dilated(h) + bias), + partial sums --------
+// grid (ceil(S/TS), B), block 256.  w: [3][C]
+__global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ t,
+                                                          float* __restrict__ part, int S, int C, int dil, int TS) {
+    __shared__ float red[8];
+    const QuadMap qm(C);
+    const int b = blockIdx.y, s0 = blockIdx.x * TS, s1 = min(s0 + TS, S);
+    const int c = 4 * qm.cq;
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + c);
+    const float* hb = h + (long)b * S * C + c;
+    float sum = 0.f, sq = 0.f;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = s0 + qm.fo; s < s1; s += qm.nf) {
+        const float4 xm = (s - dil >= 0) ? *reinterpret_cast<const float4*>(hb + (long)(s - dil) * C) : z;
+        const float4 x0 = *reinterpret_cast<const float4*>(hb + (long)s * C);
+        const float4 xp = (s + dil < S) ? *reinterpret_cast<const float4*>(hb + (long)(s + dil) * C) : z;
+        float4 v;
+        v.x = silu_f(w0.x * xm.x + w1.x * x0.x + w2.x * xp.x + bs.x);
+        v.y = silu_f(w0.y * xm.y + w1.y * x0.y + w2.y * xp.y + bs.y);
+        v.z = silu_f(w0.z * xm.z + w1.z * x0.z + w2.z * xp.z + bs.z);
+        v.w = silu_f(w0.w * xm.w + w1.w * x0.w + w2.w * xp.w + bs.w);
+        *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+        sum += v.x + v.y + v.z + v.w;
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
+}
+
+// ---- final LayerNorm (eps, affine) in place + partial sums of the result -----
+// grid (ceil(S/32), B), block 256: each wave normalises 8 rows.
+__global__ __launch_bounds__(256) void final_ln_kernel(float* __restrict__ x, const float* __restrict__ gw,
+                                                       const float* __restrict__ gb, float* __restrict__ part,
+                                                       int S, int C, float eps) {
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int nq = C >> 2;
+    float sum = 0.f, sq = 0.f;
+    for (int r = 0; r < 8; ++r) {
+        const int s = blockIdx.x * 32 + wave * 8 + r;
+        if (s >= S) break;
+        float* row = x + ((long)b * S + s) * C;
+        float4 v[4];
+        float rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = lane + 64 * i;
+            v[i] = (q < nq) ? *reinterpret_cast<const float4*>(row + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+        const float mean = wave_sum(rs) / (float)C;
+        float d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < nq) {
+                const float a = v[i].x - mean, bq = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                d2 += a * a + bq * bq + c * c + d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(d2) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nq) {
+                const float4 g = *reinterpret_cast<const float4*>(gw + 4 * q);
+                const float4 o = *reinterpret_cast<const float4*>(gb + 4 * q);
+                float4 y;
+                y.x = (v[i].x - mean) * rstd * g.x + o.x;
+                y.y = (v[i].y - mean) * rstd * g.y + o.y;
+                y.z = (v[i].z - mean) * rstd * g.z + o.z;
+                y.w = (v[i].w - mean) * rstd * g.w + o.w;
+                *reinterpret_cast<float4*>(row + 4 * q) = y;
+                sum += y.x + y.y + y.z + y.w;
+                sq += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+            }
+        }
+    }
+    write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
+}
+
+// ---- out = prelu(GroupNorm(y) + skip); optional tap of the pre-PReLU value ---
+// flat over M*C/4 float4s
+__global__ void final_gn_kernel(const float* __restrict__ y, const float* __restrict__ skip,
+                                const float* __restrict__ stats, const float* __restrict__ gw,
+                                const float* __restrict__ gb, float prelu_a, float* __restrict__ out,
+                                float* __restrict__ tap, long M, int S, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = C >> 2;
+    if (i >= M * nq) return;
+    const long m = i / nq;
+    const int c = (int)(i % nq) * 4;
+    const int b = (int)(m / S);
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const float4 v = *reinterpret_cast<const float4*>(y + m * C + c);
+    const float4 k = *reinterpret_cast<const float4*>(skip + m * C + c);
+    const float4 g = *reinterpret_cast<const float4*>(gw + c);
+    const float4 o = *reinterpret_cast<const float4*>(gb + c);
+    float4 r;
+    r.x = (v.x - mean) * rstd * g.x + o.x + k.x;
+    r.y = (v.y - mean) * rstd * g.y + o.y + k.y;
+    r.z = (v.z - mean) * rstd * g.z + o.z + k.z;
+    r.w = (v.w - mean) * rstd * g.w + o.w + k.w;
+    if (tap) *reinterpret_cast<float4*>(tap + m * C + c) = r;
+    r.x = r.x >= 0.f ? r.x : prelu_a * r.x;
+    r.y = r.y >= 0.f ? r.y : prelu_a * r.y;
+    r.z = r.z >= 0.f ? r.z : prelu_a * r.z;
+    r.w = r.w >= 0.f ? r.w : prelu_a * r.w;
+    *reinterpret_cast<float4*>(out + m * C + c) = r;
+}
+
+// ---- decoder stage 1: fv[m][k] = sum_c sep[m][c] * W[c][k], one wave per frame
+// dynamic LDS: C * 20 floats (rows padded to 20 so float4 reads are conflict-free)
+__global__ __launch_bounds__(256) void decoder_frames_kernel(const float* __restrict__ sep, const float* __restrict__ w,
+                                                             float* __restrict__ fv, long M, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    for (int i = threadIdx.x; i < C * 16; i += 256) sw[(i >> 4) * 20 + (i & 15)] = w[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xv = sep[m * C + c];
+            const float4* wr = reinterpret_cast<const float4*>(sw + c * 20);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 wv = wr[j];
+                acc[4 * j + 0] += xv * wv.x; acc[4 * j + 1] += xv * wv.y;
+                acc[4 * j + 2] += xv * wv.z; acc[4 * j + 3] += xv * wv.w;
+            }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float v = wave_sum(acc[k]);
+            if (lane == k) mine = v;
+        }
+        if (lane < 16) fv[m * 16 + lane] = mine;
+    }
+}
+
+// ---- decoder stage 2: overlap-add of frame vectors, zero pad / trim to T -----
+__global__ void decoder_ola_kernel(const float* __restrict__ fv, float* __restrict__ est, int B, int S, int T) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T) return;
+    const int b = (int)(i / T), t = (int)(i % T);
+    const int f1 = t >> 3, k = t & 7;
+    float v = 0.f;
+    if (f1 < S) v += fv[((long)b * S + f1) * 16 + k];
+    if (f1 >= 1 && f1 - 1 < S) v += fv[((long)b * S + f1 - 1) * 16 + k + 8];
+    est[i] = v;
+}
+
+}  // namespace msf2

@@ -1,0 +1,154 @@
+"""Drop-in ``nn.Module`` for the reference's separation network.
+
+``MossFormer2_SS(args).model`` in the reference is a ``MossFormer`` module
+(reference: models/mossformer2/mossformer2.py:648-757) whose callers do
+``model.to(device); reload_for_eval(model, dir, use_cuda); model.eval();
+out_list = model(inputs)`` (reference: inference.py:21-26, app.py:175-181,
+utils/decode.py:62,73).  ``MossFormerHIP`` offers the same surface:
+
+* ``state_dict()`` / ``load_state_dict()`` with exactly the reference's key
+  names, shapes and order (a skeleton of empty sub-modules carries the
+  parameters; it has no forward of its own);
+* ``__call__(x[B, T]) -> list of num_spks tensors [B, T]`` on the device and
+  dtype of ``x``;
+* the compute always runs on the module's MI355X (``compute_device``) through
+  libmsf2 -- a CPU input (the Flask app pins ``device='cpu'``, reference:
+  app.py:166-170) is copied over and the result copied back.
+
+The forward is re-entrant: packed weights are read-only and every call takes
+its own workspace from torch's caching allocator (the reference's Flask server
+is threaded and shares one model object, reference: app.py:256-259).
+"""
+import threading
+
+import torch
+from torch import nn
+
+from . import _lib
+from .config import MossFormer2Config
+from .packing import PackedWeights
+from .schema import state_dict_schema
+from .synth import make_state_dict
+
+_BUFFERS = ("pos_enc.inv_freq",)
+_FROZEN = ("rotary_pos_emb.freqs",)
+
+
+def _attach(root: nn.Module, key: str, tensor: torch.Tensor):
+    parts = key.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    if any(key.endswith(b) for b in _BUFFERS):
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        frozen = any(key.endswith(f) for f in _FROZEN)
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=not frozen))
+
+
+class MossFormerHIP(nn.Module):
+    def __init__(self, cfg: MossFormer2Config, compute_device=None, precision=_lib.PREC_FP32, init_seed=0):
+        super().__init__()
+        self.cfg = cfg
+        self.num_spks = cfg.num_spks
+        self.precision = precision
+        self._compute_device = compute_device
+        # deterministic, non-degenerate initial weights (a checkpoint normally replaces them)
+        init = make_state_dict(cfg, init_seed)
+        for key, shape in state_dict_schema(cfg).items():
+            _attach(self, key, torch.from_numpy(init[key]).reshape(shape).clone())
+        self._packed = None
+        self._pack_lock = threading.Lock()
+        self._lib = None
+
+    # -- weight life-cycle ------------------------------------------------------
+    def _invalidate(self):
+        self._packed = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return r
+
+    @property
+    def compute_device(self) -> torch.device:
+        if self._compute_device is not None:
+            return torch.device(self._compute_device)
+        p = next(self.parameters())
+        if p.device.type == "cuda":
+            return p.device
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def packed(self) -> PackedWeights:
+        pk = self._packed
+        if pk is None:
+            with self._pack_lock:
+                pk = self._packed
+                if pk is None:
+                    if not torch.cuda.is_available():
+                        raise _lib.Msf2Error("no MI355X visible: the separation forward has no CPU path")
+                    self._lib = _lib.load()
+                    pk = PackedWeights(super().state_dict(), self.cfg, self.compute_device, self.precision)
+                    self._packed = pk
+        return pk
+
+    # -- forward ------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, taps: dict = None):
+        if x.dim() != 2:
+            raise ValueError("expected input of shape [batch, samples]")
+        pk = self.packed()
+        lib = self._lib
+        dev = pk.device
+        src_device, src_dtype = x.device, x.dtype
+        B, T = x.shape
+        if T < self.cfg.enc_kernel:
+            raise ValueError(f"input shorter than the encoder kernel ({T} < {self.cfg.enc_kernel})")
+        with torch.cuda.device(dev):
+            xin = x.detach().to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+            out = torch.empty((self.num_spks, B, T), device=dev, dtype=torch.float32)
+            nbytes = lib.msf2_workspace_bytes(pk.c_cfg, B, T)
+            if nbytes == 0:
+                raise _lib.Msf2Error("msf2_workspace_bytes rejected the configuration")
+            ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            tp = None
+            tap_bufs = {}
+            if taps is not None:
+                S = lib.msf2_num_frames(T)
+                tp = _lib.Taps()
+                for name, _ in _lib.Taps._fields_:
+                    tap_bufs[name] = torch.zeros((B, S, self.cfg.dim), device=dev, dtype=torch.float32)
+                    setattr(tp, name, tap_bufs[name].data_ptr())
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.msf2_forward(pk.c_cfg, pk.struct, xin.data_ptr(), out.data_ptr(), B, T,
+                                  ws.data_ptr(), nbytes, tp, stream)
+            _lib.check(rc, "msf2_forward")
+            # the workspace must outlive the kernels enqueued on `stream`
+            ws.record_stream(torch.cuda.current_stream(dev))
+            if taps is not None:
+                taps.update(tap_bufs)
+        outs = [out[s] for s in range(self.num_spks)]
+        if src_device != dev or src_dtype != torch.float32:
+            outs = [o.to(device=src_device, dtype=src_dtype) for o in outs]
+        return outs
+
+
+class MossFormer2_SS(nn.Module):
+    """Model wrapper with the reference's constructor contract: reads the
+    hyper-parameters off ``args`` and exposes the network as ``.model``
+    (reference: models/mossformer2/mossformer2.py:739-757)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.model = MossFormerHIP(MossFormer2Config.from_args(args),
+                                   precision=int(getattr(args, "msf2_precision", _lib.PREC_FP32)))
+
+    def forward(self, x):
+        return self.model(x)

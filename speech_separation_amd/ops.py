@@ -1,0 +1,117 @@
+"""Thin torch-tensor wrappers over the single-operator entry points of libmsf2
+(include/msf2.h).  Host plumbing only: shape checks, output / workspace
+allocation from torch's allocator, the current HIP stream.  Every function
+requires CUDA (HIP) fp32 contiguous tensors and raises if the library is
+missing."""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+
+
+def _chk(*ts):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("expected contiguous fp32 tensors on the GPU")
+
+
+def encoder(mix, enc_w_tapmajor, eps=1e-8):
+    """mix [B,T], enc_w [16,C] -> (enc [B,S,C], stats [B,2] = (mean, rstd))."""
+    lib = _lib.load()
+    _chk(mix, enc_w_tapmajor)
+    B, T = mix.shape
+    C = enc_w_tapmajor.shape[1]
+    S = lib.msf2_num_frames(T)
+    enc = torch.empty((B, S, C), device=mix.device)
+    stats = torch.empty((B, 2), device=mix.device)
+    n = lib.msf2_stats_ws_bytes(B, S)
+    ws = _ws(n, mix.device)
+    _lib.check(lib.msf2_encoder(mix.data_ptr(), enc_w_tapmajor.data_ptr(), enc.data_ptr(), stats.data_ptr(),
+                                eps, B, T, C, ws.data_ptr(), ws.numel(), _stream(mix)), "msf2_encoder")
+    return enc, stats
+
+
+def dwconv17(x, dw_tapmajor, out=None, accumulate=False):
+    """x [B,S,C] -> x + dwconv17(x); with accumulate, added onto `out`."""
+    lib = _lib.load()
+    _chk(x, dw_tapmajor)
+    B, S, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out)
+    _lib.check(lib.msf2_dwconv17(x.data_ptr(), C, dw_tapmajor.data_ptr(), out.data_ptr(), C, B, S, C,
+                                 int(accumulate), _stream(x)), "msf2_dwconv17")
+    return out
+
+
+def linear(x, W, b=None, shift=False, scale_norm=False, act=0, precision=_lib.PREC_FP32):
+    """x [B,S,K], W [N,K] -> act(rowscale(shift(x)) W^T + b) [B,S,N]."""
+    lib = _lib.load()
+    _chk(x, W)
+    B, S, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((B, S, N), device=x.device)
+    n = lib.msf2_linear_ws_bytes(B, S)
+    ws = _ws(n, x.device)
+    _lib.check(lib.msf2_linear(x.data_ptr(), K, W.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(),
+                               N, B, S, K, N, int(shift), int(scale_norm), act, precision, ws.data_ptr(), ws.numel(),
+                               _stream(x)), "msf2_linear")
+    return y
+
+
+def flash_attention(hu, gamma, beta, freqs, precision=_lib.PREC_FP32):
+    """hu [B,S,2E+128] = v|u|qk -> o [B,S,E]."""
+    lib = _lib.load()
+    _chk(hu, gamma, beta, freqs)
+    B, S, W = hu.shape
+    E = (W - _lib.QK_DIM) // 2
+    o = torch.empty((B, S, E), device=hu.device)
+    n = lib.msf2_flash_attention_ws_bytes(B, S, E)
+    ws = _ws(n, hu.device)
+    _lib.check(lib.msf2_flash_attention(hu.data_ptr(), W, gamma.data_ptr(), beta.data_ptr(), freqs.data_ptr(),
+                                        o.data_ptr(), B, S, E, precision, ws.data_ptr(), ws.numel(), _stream(hu)),
+               "msf2_flash_attention")
+    return o
+
+
+def gated_tcn(x, layer_weights, precision=_lib.PREC_FP32):
+    """In place on x [B,S,C]; layer_weights: a _lib.LayerWeights (from PackedWeights.layers[i])."""
+    lib = _lib.load()
+    _chk(x)
+    B, S, C = x.shape
+    n = lib.msf2_gated_tcn_ws_bytes(B, S, C)
+    ws = _ws(n, x.device)
+    _lib.check(lib.msf2_gated_tcn(x.data_ptr(), layer_weights, B, S, C, precision, ws.data_ptr(), ws.numel(),
+                                  _stream(x)), "msf2_gated_tcn")
+    return x
+
+
+def decoder(sep, dec_w, T):
+    """sep [B,S,C] (encoder output times mask), dec_w [C,16] -> est [B,T]."""
+    lib = _lib.load()
+    _chk(sep, dec_w)
+    B, S, C = sep.shape
+    est = torch.empty((B, T), device=sep.device)
+    n = lib.msf2_decoder_ws_bytes(B, S)
+    ws = _ws(n, sep.device)
+    _lib.check(lib.msf2_decoder(sep.data_ptr(), dec_w.data_ptr(), est.data_ptr(), B, S, C, T, ws.data_ptr(),
+                                ws.numel(), _stream(sep)), "msf2_decoder")
+    return est
+
+
+def tcn_pointwise(h, t, bstat, tcn_weights, precision=_lib.PREC_FP32):
+    """h, t [B,S,C]; bstat [B,2]; tcn_weights: a _lib.TcnWeights -> new h (one kernel launch)."""
+    lib = _lib.load()
+    _chk(h, t, bstat)
+    B, S, C = h.shape
+    out = torch.empty_like(h)
+    _lib.check(lib.msf2_tcn_pointwise(h.data_ptr(), t.data_ptr(), bstat.data_ptr(), tcn_weights, out.data_ptr(),
+                                      B, S, C, precision, _stream(h)), "msf2_tcn_pointwise")
+    return out

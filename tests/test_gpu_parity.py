@@ -1,0 +1,262 @@
+"""Parity of the HIP path (through the C ABI of libmsf2.so) against the CPU
+oracle and against golden fixtures written by the reference model.
+
+Tolerances (fp32 path).  The contract is max-abs <= 1e-3 on the separated
+waveforms against the reference CPU forward; the tests hold the HIP path to
+tighter, scale-aware bounds: single operators to 2e-5 relative to the tensor's
+peak, the tiny/small models to 1e-5 absolute on outputs of rms ~5e-3, the
+24-layer model to 1e-3 of the output peak (the level at which the fp32
+reference itself differs from an fp64 evaluation of the same weights).
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref  # noqa: E402  (checker only)
+from speech_separation_amd import _lib, ops  # noqa: E402
+from speech_separation_amd.config import TINY, SMALL, FULL_8K  # noqa: E402
+from speech_separation_amd.model import MossFormerHIP  # noqa: E402
+from speech_separation_amd.packing import PackedWeights  # noqa: E402
+from speech_separation_amd.schema import MDL  # noqa: E402
+from speech_separation_amd.synth import make_state_dict, synth_batch  # noqa: E402
+
+CFG = {"tiny": TINY, "small": SMALL, "full": FULL_8K}
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp(min=1e-30))
+
+
+@pytest.fixture(scope="module")
+def models():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            m = MossFormerHIP(CFG[name], compute_device=DEV)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(CFG[name], 0).items()})
+            cache[name] = m
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope="module")
+def small_w():
+    return cpu_ref.to_torch(make_state_dict(SMALL, 0))
+
+
+# ------------------------------------------------------------------ operators
+@pytest.mark.parametrize("B,T,C", [(1, 4000, 64), (3, 8003, 128), (2, 16000, 512)])
+def test_encoder(B, T, C):
+    g = torch.Generator().manual_seed(1)
+    mix = torch.randn(B, T, generator=g) * 0.1
+    w = torch.randn(C, 1, 16, generator=g) * 0.25
+    ref = torch.relu(torch.nn.functional.conv1d(mix[:, None], w, stride=8)).transpose(1, 2)
+    enc, stats = ops.encoder(mix.to(DEV), w[:, 0, :].t().contiguous().to(DEV), eps=1e-8)
+    assert rel_err(enc, ref) <= 2e-6
+    mu = ref.double().mean(dim=(1, 2))
+    var = ref.double().var(dim=(1, 2), unbiased=False)
+    assert np.allclose(stats[:, 0].cpu().double(), mu, rtol=1e-5, atol=1e-7)
+    assert np.allclose(stats[:, 1].cpu().double(), 1 / torch.sqrt(var + 1e-8), rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,S,C", [(1, 7, 64), (2, 499, 384), (2, 1000, 2176), (1, 33, 512)])
+def test_dwconv17(B, S, C):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, S, C, generator=g)
+    w = torch.randn(C, 1, 17, generator=g) * 0.2
+    ref = x + cpu_ref.dwconv_time(x, w)
+    wt = w[:, 0, :].t().contiguous().to(DEV)
+    got = ops.dwconv17(x.to(DEV), wt)
+    assert rel_err(got, ref) <= 2e-6
+    base = torch.randn(B, S, C, generator=g)
+    got2 = ops.dwconv17(x.to(DEV), wt, out=base.to(DEV).clone(), accumulate=True)
+    assert rel_err(got2, base + ref) <= 2e-6
+
+
+@pytest.mark.parametrize("B,S,K,N,shift,sn,act", [
+    (1, 100, 64, 64, False, False, 0), (2, 499, 64, 384, True, True, 1), (2, 300, 512, 2176, True, True, 1),
+    (1, 129, 1024, 512, False, True, 1), (3, 128, 128, 96, False, False, 2)])
+def test_linear(B, S, K, N, shift, sn, act):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, S, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    xr = cpu_ref.token_shift(x) if shift else x
+    if sn:
+        xr = cpu_ref.scale_norm(xr, torch.ones(1))
+    ref = xr.double() @ W.double().t() + b.double()
+    ref = [lambda t: t, torch.nn.functional.silu, torch.sigmoid][act](ref)
+    got = ops.linear(x.to(DEV), W.to(DEV), b.to(DEV), shift=shift, scale_norm=sn, act=act)
+    assert rel_err(got, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("B,S,E", [(1, 256, 128), (2, 499, 128), (1, 1000, 256), (2, 700, 1024)])
+def test_flash_attention(B, S, E):
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn(B, S, E, generator=g)
+    u = torch.randn(B, S, E, generator=g)
+    qk = torch.randn(B, S, 128, generator=g)
+    gam = 2.0 + 0.1 * torch.randn(4, 128, generator=g)
+    bet = 0.1 * torch.randn(4, 128, generator=g)
+    freqs = torch.from_numpy(make_state_dict(TINY)[f"{MDL}.layers.0.rotary_pos_emb.freqs"])
+    ref = cpu_ref.attention_core(v.double(), u.double(), qk.double(), gam.double(), bet.double(), freqs.double())
+    hu = torch.cat((v, u, qk), -1).contiguous()
+    got = ops.flash_attention(hu.to(DEV), gam.to(DEV), bet.to(DEV), freqs.to(DEV))
+    assert rel_err(got, ref) <= 2e-5
+
+
+def test_gated_tcn(small_w):
+    g = torch.Generator().manual_seed(5)
+    B, S, C = 2, 777, SMALL.dim
+    x = torch.randn(B, S, C, generator=g)
+    W64 = {k: v.double() for k, v in small_w.items()}
+    ref = cpu_ref.gated_tcn(x.double(), W64, f"{MDL}.fsmn.1")
+    pk = PackedWeights(small_w, SMALL, DEV)
+    got = ops.gated_tcn(x.to(DEV).clone(), pk.layers[1])
+    assert rel_err(got, ref) <= 2e-5
+
+
+def test_tcn_pointwise(small_w):
+    g = torch.Generator().manual_seed(7)
+    B, S, C = 2, 300, SMALL.dim
+    h = torch.randn(B, S, C, generator=g)
+    t = torch.nn.functional.silu(torch.randn(B, S, C, generator=g))
+    p = f"{MDL}.fsmn.0.tcn.3"
+    W = {k: v.double() for k, v in small_w.items() if k.startswith(p)}
+    tn = cpu_ref.group_norm1(t.double(), W[f"{p}.net.2.weight"], W[f"{p}.net.2.bias"], 1e-5)
+    net = tn @ W[f"{p}.net.3.weight"][:, :, 0].t() + W[f"{p}.net.3.bias"]
+    gate = torch.sigmoid(h.double() @ W[f"{p}.gate.0.weight"][:, :, 0].t() + W[f"{p}.gate.0.bias"])
+    ref = h.double() + gate * net
+    mu = t.double().mean(dim=(1, 2))
+    rstd = 1 / torch.sqrt(t.double().var(dim=(1, 2), unbiased=False) + 1e-5)
+    bstat = torch.stack((mu, rstd), 1).float().contiguous()
+    pk = PackedWeights(small_w, SMALL, DEV)
+    got = ops.tcn_pointwise(h.to(DEV), t.to(DEV), bstat.to(DEV), pk.layers[0].tcn[3])
+    assert rel_err(got, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("B,S,C,T", [(1, 499, 64, 4000), (2, 999, 512, 8003), (1, 100, 128, 700)])
+def test_decoder(B, S, C, T):
+    g = torch.Generator().manual_seed(6)
+    sep = torch.randn(B, S, C, generator=g)
+    w = torch.randn(C, 1, 16, generator=g) * 0.1
+    est = torch.nn.functional.conv_transpose1d(sep.double().transpose(1, 2), w.double(), stride=8)[:, 0, :]
+    ref = torch.zeros(B, T, dtype=torch.float64)
+    n = min(T, est.shape[1])
+    ref[:, :n] = est[:, :n]
+    got = ops.decoder(sep.to(DEV), w[:, 0, :].contiguous().to(DEV), T)
+    assert rel_err(got, ref) <= 2e-6
+
+
+def test_bad_arguments_are_rejected():
+    lib = _lib.load()
+    cfg = _lib.Config(96, 2, 16, 2, _lib.PREC_FP32)     # dim not supported
+    assert lib.msf2_workspace_bytes(cfg, 1, 8000) == 0
+    assert lib.msf2_forward(cfg, None, None, None, 1, 8000, None, 0, None, None) == -1
+    x = torch.zeros(1, 10, 64, device=DEV)
+    with pytest.raises(_lib.Msf2Error):
+        ops.linear(x[..., :48].contiguous(), torch.zeros(8, 48, device=DEV))   # K not a multiple of 32
+    m = MossFormerHIP(TINY, compute_device=DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 8, device=DEV))
+
+
+def test_workspace_too_small_is_reported(models):
+    lib = _lib.load()
+    m = models("tiny")
+    pk = m.packed()
+    x = torch.zeros(1, 4000, device=DEV)
+    out = torch.zeros(2, 1, 4000, device=DEV)
+    ws = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = lib.msf2_forward(pk.c_cfg, pk.struct, x.data_ptr(), out.data_ptr(), 1, 4000, ws.data_ptr(), 1024, None, None)
+    assert rc == -2
+
+
+# -------------------------------------------------------------- whole forward
+def test_forward_taps_against_reference(models, golden_dir):
+    z = np.load(os.path.join(golden_dir, "fwd_tiny_B1_T4000.npz"))
+    taps = {}
+    out = models("tiny")(torch.from_numpy(z["input"]).to(DEV), taps=taps)
+    torch.cuda.synchronize()
+    for name in ("enc", "x0", "flash0", "tcn0", "mdl", "mask0", "mask1"):
+        ref = torch.from_numpy(z[f"tap_{name}"])
+        assert rel_err(taps[name], ref) <= 3e-5, name
+    got = torch.stack(out, 0).cpu().numpy()
+    assert np.abs(got - z["out"]).max() <= 1e-5
+
+
+def test_forward_matches_reference_fixtures(models, golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "fwd_*.npz")))
+    seen = 0
+    for f in files:
+        name = re.match(r"fwd_(\w+?)_B", os.path.basename(f)).group(1)
+        if name == "full":
+            continue
+        z = np.load(f)
+        out = models(name)(torch.from_numpy(z["input"]).to(DEV))
+        got = torch.stack(out, 0).cpu().numpy()
+        assert got.shape == z["out"].shape
+        assert np.abs(got - z["out"]).max() <= 1e-5, f
+        seen += 1
+    assert seen >= 7
+
+
+def test_full_model_matches_reference(models, golden_dir):
+    z = np.load(os.path.join(golden_dir, "fwd_full_B1_T32000.npz"))
+    out = models("full")(torch.from_numpy(z["input"]).to(DEV))
+    got = torch.stack(out, 0).cpu().numpy()
+    peak = np.abs(z["out"]).max()
+    err = np.abs(got - z["out"]).max()
+    err64 = np.abs(got - z["out_f64"]).max()
+    print(f"full model: max-abs vs reference fp32 {err:.3e}, vs fp64 evaluation {err64:.3e}, peak {peak:.3e}")
+    assert err <= 1e-3                      # the stated contract, raw outputs
+    assert err <= 1e-3 * peak               # and on the peak-normalised scale
+    assert err64 <= 1e-3 * peak
+
+
+def test_cpu_input_round_trip(models, golden_dir):
+    """A CPU tensor in gives CPU tensors out (the Flask entry point feeds CPU tensors)."""
+    z = np.load(os.path.join(golden_dir, "fwd_tiny_B1_T8000.npz"))
+    out = models("tiny")(torch.from_numpy(z["input"]))
+    assert all(o.device.type == "cpu" and o.shape == (1, 8000) for o in out)
+    assert np.abs(torch.stack(out, 0).numpy() - z["out"]).max() <= 1e-5
+
+
+# -------------------------------------------------- size-independent properties
+def test_full_size_batch_properties(models):
+    """At the benchmark size (16 x 4 s, 24 layers): utterances in a batch are
+    independent, the result is deterministic, and scaling the input by a
+    power of two leaves the peak-normalised output unchanged only through the
+    homogeneity of the network's linear/normalised parts -- checked here as
+    batch-vs-single agreement and bitwise repeatability."""
+    m = models("full")
+    x = torch.from_numpy(synth_batch(16, 32000, seed0=0)).to(DEV)
+    a = torch.stack(m(x), 0)
+    b = torch.stack(m(x), 0)
+    assert torch.equal(a, b)                                     # deterministic
+    assert torch.isfinite(a).all()
+    single = torch.stack(m(x[5:6]), 0)
+    peak = float(a.abs().max())
+    assert float((a[:, 5:6] - single).abs().max()) <= 1e-5 * peak   # batch independence
+    perm = torch.arange(15, -1, -1, device=DEV)
+    c = torch.stack(m(x[perm]), 0)
+    assert float((c[:, perm] - a).abs().max()) <= 1e-5 * peak       # permutation equivariance
+
+
+def test_long_form_runs(models):
+    """60 s input after the decode padding rule: 492000 samples, 241 groups."""
+    m = models("full")
+    x = torch.from_numpy(synth_batch(1, 492000, seed0=3)).to(DEV)
+    out = torch.stack(m(x), 0)
+    assert out.shape == (2, 1, 492000)
+    assert torch.isfinite(out).all()
+    assert float(out.abs().max()) > 0

@@ -1,0 +1,162 @@
+"""CPU-side tests: the C-ABI library loads and exports what include/msf2.h
+declares, and the host logic (module skeleton, checkpoint reload, decode
+harness, sharding) behaves like the reference's.  No kernel is launched."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from speech_separation_amd import _lib
+from speech_separation_amd.checkpoint import reload_for_eval
+from speech_separation_amd.config import TINY, FULL_8K, MossFormer2Config
+from speech_separation_amd.decode import decode_one_audio, padded_length
+from speech_separation_amd.model import MossFormerHIP, MossFormer2_SS
+from speech_separation_amd.schema import state_dict_schema
+from speech_separation_amd.synth import make_state_dict, synth_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Args:
+    network = "MossFormer2_SS_8K"
+    sampling_rate = 8000
+    decode_window = 1
+    one_time_decode_length = 60
+    num_spks = 2
+    encoder_kernel_size = 16
+    encoder_embedding_dim = 64
+    mossformer_sequence_dim = 64
+    num_mossformer_layer = 2
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "msf2.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(msf2_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()                       # raises if the .so or a symbol is missing
+    assert lib.msf2_version() >= 1
+    assert lib.msf2_num_frames(32000) == 3999
+    assert lib.msf2_strerror(-2).decode() == "workspace too small"
+
+
+def test_workspace_query_runs_without_gpu():
+    lib = _lib.load()
+    cfg = _lib.Config(512, 24, 16, 2, _lib.PREC_FP32)
+    n1 = lib.msf2_workspace_bytes(cfg, 1, 32000)
+    n16 = lib.msf2_workspace_bytes(cfg, 16, 32000)
+    assert 0 < n1 < n16 < 16 * (1 << 30)
+    assert lib.msf2_workspace_bytes(_lib.Config(512, 24, 16, 3, 0), 1, 32000) == 0   # 3 speakers unsupported
+
+
+def test_struct_sizes_match_header_layout():
+    import ctypes as C
+    lib = _lib.load()
+    for which, st in enumerate((_lib.Config, _lib.TcnWeights, _lib.LayerWeights, _lib.Weights, _lib.Taps)):
+        assert lib.msf2_sizeof(which) == C.sizeof(st), st
+    assert lib.msf2_sizeof(99) == -1
+
+
+def test_state_dict_schema_and_counts():
+    sch = state_dict_schema(FULL_8K)
+    assert len(sch) == 2107
+    numel = sum(int(np.prod(s)) for s in sch.values())
+    assert numel == 162_488_010            # parameters + inv_freq buffer + 24 rotary freqs copies
+    m = MossFormerHIP(TINY)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(state_dict_schema(TINY).keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(state_dict_schema(TINY)[k]), k
+    assert "mask_net.pos_enc.inv_freq" not in dict(m.named_parameters())
+    n_params = sum(p.numel() for p in m.parameters())
+    # the reference shares one rotary module (16 freqs, counted once: 275 480); here each layer holds its copy
+    assert n_params == 275_480 + 16
+
+
+def test_wrapper_reads_reference_arg_names():
+    w = MossFormer2_SS(Args())
+    assert isinstance(w.model, MossFormerHIP)
+    assert w.model.cfg == MossFormer2Config(dim=64, num_layers=2)
+    a = Args()
+    a.mossformer_sequence_dim = 128
+    with pytest.raises(ValueError):
+        MossFormer2_SS(a)
+
+
+def test_forward_without_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = MossFormerHIP(TINY)
+    with pytest.raises(_lib.Msf2Error):
+        m(torch.zeros(1, 4000))
+
+
+def test_reload_for_eval_conventions(tmp_path, capsys):
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(TINY, 5).items()}
+    # checkpoint as the reference's trainer writes it: weights under 'model', DDP 'module.' prefix
+    ck = {"model": {"module." + k: v for k, v in sd.items()}, "epoch": 3}
+    bad = "module.mask_net.prelu.weight"
+    ck["model"][bad] = torch.zeros(7)      # wrong shape -> skipped, reported
+    torch.save(ck, tmp_path / "model.ckpt-3-100.pt")
+    (tmp_path / "last_checkpoint").write_text("other.pt\n")
+    (tmp_path / "last_best_checkpoint").write_text("model.ckpt-3-100.pt\n")
+    m = MossFormerHIP(TINY)
+    before = m.state_dict()["mask_net.prelu.weight"].clone()
+    reload_for_eval(m, str(tmp_path), use_cuda=0)
+    out = capsys.readouterr().out
+    assert "mask_net.prelu.weight not loaded" in out
+    got = m.state_dict()
+    assert torch.equal(got["mask_net.prelu.weight"], before)
+    for k in sd:
+        if k != "mask_net.prelu.weight":
+            assert torch.equal(got[k], sd[k]), k
+    # no pointer file: warning, weights untouched
+    reload_for_eval(m, str(tmp_path / "nope"), use_cuda=0)
+    assert "Warning" in capsys.readouterr().out
+
+
+def test_decode_harness_on_cpu_model(golden_dir):
+    """Host logic of the decode harness with the oracle standing in for the model."""
+    z = np.load(os.path.join(golden_dir, "decode_tiny.npz"))
+    W = cpu_ref.to_torch(make_state_dict(TINY, 0))
+
+    def model(x):
+        with torch.no_grad():
+            return cpu_ref.forward(W, x, TINY)
+    a = Args()
+    for T in (4000, 8000, 10000, 28400, 32000):
+        out = decode_one_audio(model, torch.device("cpu"), z[f"in_{T}"], a)
+        got = np.stack(out, 0)
+        assert got.dtype == np.float32
+        assert np.abs(got - z[f"out_{T}"]).max() <= 2e-4
+    a.one_time_decode_length = 2
+    out = decode_one_audio(model, torch.device("cpu"), z["in_seg_20001"], a)
+    got = np.stack(out, 0)
+    assert got.dtype == np.float64 and got.shape == (2, 28002)
+    assert np.abs(got - z["out_seg_20001"]).max() <= 2e-4
+    a.network = "something_else"
+    assert decode_one_audio(model, torch.device("cpu"), z["in_4000"], a) is None
+
+
+def test_padded_length_table():
+    for t, want in ((4000, 8000), (8000, 14000), (10000, 14000), (14000, 14000), (20000, 20000),
+                    (28400, 38800), (32000, 32000), (480000, 492000), (480001, 492002)):
+        assert padded_length(t, 8000, 6000) == want
+
+
+def test_flops_formula():
+    # 1.5109 TFLOP per 4-s utterance, 377.7 GFLOP per audio-second
+    assert FULL_8K.flops(32000) == pytest.approx(2 * (175_217_664 * 3999 + 13_369_344 * 4096))
+    assert FULL_8K.frames(32000) == 3999 and FULL_8K.padded_frames(32000) == 4096
+
+
+def test_synth_mixture_shape_and_level():
+    x = synth_batch(2, 8000, seed0=0)
+    assert x.shape == (2, 8000) and x.dtype == np.float32
+    assert np.abs(x).max() <= 1.0
+    rms = np.sqrt((x ** 2).mean())
+    assert 0.03 < rms < 0.2
+    assert np.array_equal(x, synth_batch(2, 8000, seed0=0))
