@@ -89,6 +89,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise Msf2Error(f"{LIB_PATH} not found: build it with `python -m speech_separation_amd.build` "
                         "(hipcc, gfx950). There is no fallback compute path.")
+    # torch ships its own libamdhip64.so.7; load it first so that libmsf2.so binds to
+    # the SAME HIP runtime (streams and device pointers are shared with torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:
