@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsf2.so")
+LIB_PATH = os.environ.get("MSF2_LIB", os.path.join(_HERE, "lib", "libmsf2.so"))   # override: A/B builds
 
 TCN_DEPTH = 8
 QK_DIM = 128

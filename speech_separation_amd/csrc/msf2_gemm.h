@@ -5,9 +5,26 @@
 // the accumulators (epilogue).  Block tile 128x128, K step 32, 256 threads =
 // 4 waves; each wave owns a 64x64 (2x2 waves) or 32x128 (4x1 waves) sub-tile
 // as 32x32 MFMA accumulators.  Operand tiles are staged global -> registers ->
-// LDS (double buffered, one barrier per K step) in a k-major image
-// [k][row] so that the MFMA operands (one fp32 per lane, lane = row, lane
-// half = k parity) are conflict-free ds_read_b32.
+// LDS (double buffered, one barrier per K step).
+//
+// LDS image and k order.  The MFMA takes one fp32 per lane per operand: lane
+// l supplies row (l & 31) at k index (l >> 5).  The sum over k does not care
+// about order as long as A and B agree, so within each chunk of 8 k values
+// the lower lane half takes k = 0..3 and the upper half k = 4..7, one per
+// MFMA: a lane then needs 4 CONSECUTIVE k of its row per chunk, i.e. one
+// ds_read_b128 per operand tile per 4 MFMA steps from a row-major image
+// [row][32 + 4 pad] (pitch 36 floats: the 16 rows of a ds_read_b128 lane group
+// fall on 16 distinct 16-byte slots of the 256-byte bank row).  Operands that
+// are row-contiguous in global memory (time-major sources) keep a k-major
+// image [k][128 + 4] and read the same k order with four ds_read_b32.
+// Fragments of chunk c+1 are read while the MFMAs of chunk c issue.
+//
+// Operand fetches are UNCONDITIONAL loads from clamped addresses; where a zero
+// is semantically required (token shift at frame 0, time steps past the end of
+// a split, key rows past the end of an utterance) the loaded value is
+// multiplied by a 0/1 mask.  Predicated loads with a zero-filled default make
+// hipcc wait for the load inside the fetch sequence, which exposes the whole
+// memory latency once per K step.
 #pragma once
 #include "msf2_common.h"
 
@@ -15,9 +32,10 @@ namespace msf2 {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 enum { ORI_KC = 0, ORI_RC = 1 };   // operand tile is k-contiguous / row-contiguous in global memory
-// row pitch of the k-major LDS image: 130 makes the transposing scalar stores
-// of a k-contiguous source 2-way (free); 132 keeps float4 row stores 16-B aligned.
-template <int ORI> struct LdsPitch { static constexpr int v = (ORI == ORI_KC) ? 130 : 132; };
+template <int ORI> struct LdsTile {
+    static constexpr int PITCH = (ORI == ORI_KC) ? (BK + 4) : (BM + 4);
+    static constexpr int SIZE = (ORI == ORI_KC) ? BM * (BK + 4) : BK * (BM + 4);   // floats
+};
 
 template <int ORI>
 __device__ __forceinline__ void tile_coords(int tid, int i, int& r, int& k) {
@@ -30,22 +48,28 @@ template <int ORI>
 __device__ __forceinline__ void lds_put(float* s, int tid, int i, const float4& v) {
     int r, k;
     tile_coords<ORI>(tid, i, r, k);
-    constexpr int LD = LdsPitch<ORI>::v;
-    if (ORI == ORI_KC) {
-        s[(k + 0) * LD + r] = v.x;
-        s[(k + 1) * LD + r] = v.y;
-        s[(k + 2) * LD + r] = v.z;
-        s[(k + 3) * LD + r] = v.w;
-    } else {
-        *reinterpret_cast<float4*>(&s[k * LD + r]) = v;
-    }
+    constexpr int LD = LdsTile<ORI>::PITCH;
+    if (ORI == ORI_KC) *reinterpret_cast<float4*>(&s[r * LD + k]) = v;
+    else               *reinterpret_cast<float4*>(&s[k * LD + r]) = v;
 }
+
+// the 4 operand values lane (row, kh) feeds to the 4 MFMA steps of chunk c
+template <int ORI>
+__device__ __forceinline__ float4 frag_read(const float* s, int row, int c, int kh) {
+    constexpr int LD = LdsTile<ORI>::PITCH;
+    const int k = c * 8 + kh * 4;
+    if (ORI == ORI_KC) return *reinterpret_cast<const float4*>(&s[row * LD + k]);
+    return make_float4(s[(k + 0) * LD + row], s[(k + 1) * LD + row], s[(k + 2) * LD + row], s[(k + 3) * LD + row]);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
+__device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 template <class P, int SEG, int TM, int TN>
 __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* smB,
                                             f32x16 (&acc)[TM][TN], int tid, int lane, int wr, int wc) {
-    constexpr int LDA = LdsPitch<P::A_ORI>::v, LDB = LdsPitch<P::B_ORI>::v;
-    constexpr int SZA = BK * LDA, SZB = BK * LDB;
+    constexpr int SZA = LdsTile<P::A_ORI>::SIZE, SZB = LdsTile<P::B_ORI>::SIZE;
     const int nk = prob.nk(SEG);
     float4 ra[4], rb[4];
     auto fetch = [&](int kt) {
@@ -53,9 +77,9 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
         for (int i = 0; i < 4; ++i) {
             int r, k;
             tile_coords<P::A_ORI>(tid, i, r, k);
-            ra[i] = prob.fetchA(SEG, r, kt * BK + k);
+            ra[i] = prob.fetchA(SEG, kt, r, k);
             tile_coords<P::B_ORI>(tid, i, r, k);
-            rb[i] = prob.fetchB(SEG, r, kt * BK + k);
+            rb[i] = prob.fetchB(SEG, kt, r, k);
         }
     };
     auto put = [&](int buf) {
@@ -69,34 +93,56 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
     put(0);
     __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) fetch(kt + 1);
-        const float* a = smA + cur * SZA + kh * LDA + wr * (TM * 32) + l31;
-        const float* b = smB + cur * SZB + kh * LDB + wc * (TN * 32) + l31;
+    const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
+    auto compute = [&](int cur) {
+        const float* sa = smA + cur * SZA;
+        const float* sb = smB + cur * SZB;
+        float4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int t = 0; t < TM; ++t) af[0][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, 0, kh);
 #pragma unroll
-            for (int t = 0; t < TM; ++t) af[t] = a[kk * LDA + t * 32];
+        for (int t = 0; t < TN; ++t) bf[0][t] = frag_read<P::B_ORI>(sb, rowB + t * 32, 0, kh);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) bf[t] = b[kk * LDB + t * 32];
+        for (int c = 0; c < BK / 8; ++c) {
+            if (c + 1 < BK / 8) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int t = 0; t < TM; ++t) af[(c + 1) & 1][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, c + 1, kh);
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm], bf[tn], acc[tm][tn], 0, 0, 0);
+                for (int t = 0; t < TN; ++t) bf[(c + 1) & 1][t] = frag_read<P::B_ORI>(sb, rowB + t * 32, c + 1, kh);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(af[c & 1][tm], j), f4get(bf[c & 1][tn], j),
+                                                                           acc[tm][tn], 0, 0, 0);
         }
-        if (kt + 1 < nk) put(cur ^ 1);
+    };
+    // steady state has no conditional around fetch/put (a conditional makes hipcc
+    // merge register assignments with moves that wait on the loads); last tile peeled
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+#ifndef MSF2_DIAG_NOFETCH
+        fetch(kt + 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs that hide their latency
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef MSF2_DIAG_NOPUT
+        put(cur ^ 1);
+#endif
         __syncthreads();
     }
+    compute((nk - 1) & 1);
+    __syncthreads();
 }
 
 template <class P>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args args) {
-    constexpr int LDA = LdsPitch<P::A_ORI>::v, LDB = LdsPitch<P::B_ORI>::v;
-    __shared__ __attribute__((aligned(16))) float smA[2 * BK * LDA];
-    __shared__ __attribute__((aligned(16))) float smB[2 * BK * LDB];
+    __shared__ __attribute__((aligned(16))) float smA[2 * LdsTile<P::A_ORI>::SIZE];
+    __shared__ __attribute__((aligned(16))) float smB[2 * LdsTile<P::B_ORI>::SIZE];
     P prob;
     prob.init(args);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +159,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
     run_segment<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wr, wc);
     if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wr, wc);
+#ifdef MSF2_DIAG_NOEPI
+    {   // timing-only build: keep the accumulators alive with one store per thread
+        float sum = 0.f;
+        for (int s = 0; s < P::NSEG; ++s)
+            for (int tm = 0; tm < TM; ++tm)
+                for (int tn = 0; tn < TN; ++tn)
+                    for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
+        if (sum == 123.456f) *reinterpret_cast<float*>(smA) = sum;
+    }
+#else
     prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+#endif
 }
 
 // tile-local coordinates of accumulator register `reg` of MFMA tile (tm, tn)
@@ -163,79 +220,108 @@ struct ProjNT {
         n0 = blockIdx.x * (PAIRED ? BN / 2 : BN);
     }
     __device__ int nk(int) const { return a.K / BK; }
-    __device__ float4 fetchA(int seg, int r, int k) const {
-        const int s = s0 + r;
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s >= a.S) return z;
+    // rows past the end of the utterance are clamped (their outputs are never stored)
+    __device__ float4 fetchA(int seg, int kt, int r, int ko) const {
+        const int s = min(s0 + r, a.S - 1);
+        const int k = kt * BK + ko;
         long row = (long)b * a.S + s;
         const float* base = (NSEG == 2 && seg == 1) ? a.A2 : a.A;
-        if (AMODE == A_SHIFT && k < (a.K >> 1)) {
-            if (s == 0) return z;
-            row -= 1;
+        float m = 1.f;
+        if (AMODE == A_SHIFT) {
+            // first half of the features comes from the previous frame, zero at frame 0
+            const bool sh = k < (a.K >> 1);
+            row -= (sh && s > 0) ? 1 : 0;
+            m = (sh && s == 0) ? 0.f : 1.f;
         }
-        float4 v = *reinterpret_cast<const float4*>(base + row * a.lda + k);
+        float4 v = ld4(base + row * a.lda + k);
+        if (AMODE == A_SHIFT) v = mul4(v, m);
         if (AMODE == A_MUL) {
-            const float4 g = *reinterpret_cast<const float4*>(a.A2 + row * a.lda + k);
+            const float4 g = ld4(a.A2 + row * a.lda + k);
             v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
         }
         return v;
     }
-    __device__ float4 fetchB(int seg, int c, int k) const {
+    __device__ float4 fetchB(int seg, int kt, int c, int ko) const {
         const float* w = a.W;
         int n = n0 + c;
         if (PAIRED && c >= BN / 2) { n -= BN / 2; w = a.W2; }
         if (NSEG == 2 && seg == 1) w = a.W2;
-        if (n >= a.N) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(w + (long)n * a.K + k);
+        n = min(n, a.N - 1);
+        return ld4(w + (long)n * a.K + kt * BK + ko);
     }
+    // Loads are issued in batches of 16 from clamped addresses (no branch between
+    // them), so their latency overlaps; only the stores are predicated.
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane) const {
         float mean_b = 0.f, rstd_b = 1.f;
         if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
         constexpr int TNE = PAIRED ? TN / 2 : TN;
+        constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);
+        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || EPI == EPI_TCN);
+        const bool has_rs = a.rowstat != nullptr;
 #pragma unroll
-        for (int tn = 0; tn < TNE; ++tn) {
-            const int cl = MSF2_ACC_COL(wc, TN, tn, lane);
-            const int n = n0 + cl;
-            if (n >= a.N) continue;
-            const float bias = a.bias ? a.bias[n] : 0.f;
-            const float bias2 = (EPI == EPI_TANH_SIG) ? a.bias2[n] : 0.f;
-            const float c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c1[n] : 0.f;
-            const float c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c2[n] : 0.f;
+        for (int tm = 0; tm < TM; ++tm) {
+            long mrow[16];
+            bool ok[16];
+            float r0[16], r1[16];
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
+            for (int reg = 0; reg < 16; ++reg) {
+                const int s = s0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
+                ok[reg] = s < a.S;
+                mrow[reg] = (long)b * a.S + min(s, a.S - 1);
+                r0[reg] = 1.f; r1[reg] = 0.f;
+            }
+            if (ROWSTAT && has_rs) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int s = s0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
-                    if (s >= a.S) continue;
-                    const long m = (long)b * a.S + s;
+                    if (EPI == EPI_RS_BIAS_ACT) r0[reg] = a.rowstat[mrow[reg]];
+                    else { r1[reg] = a.rowstat[2 * mrow[reg]]; r0[reg] = a.rowstat[2 * mrow[reg] + 1]; }
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < TNE; ++tn) {
+                const int n = n0 + MSF2_ACC_COL(wc, TN, tn, lane);
+                const bool nok = n < a.N;
+                const int nc = min(n, a.N - 1);
+                const float bias = a.bias ? a.bias[nc] : 0.f;
+                const float bias2 = (EPI == EPI_TANH_SIG) ? a.bias2[nc] : 0.f;
+                const float c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c1[nc] : 0.f;
+                const float c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c2[nc] : 0.f;
+                float rv[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) rv[reg] = RES ? a.res[mrow[reg] * a.ldr + nc] : 0.f;
+                if (EPI == EPI_NORM && a.pe) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) rv[reg] = a.pe[(mrow[reg] - (long)b * a.S) * a.N + nc];
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
                     const float x = acc[0][tm][tn][reg];
                     float v;
                     if constexpr (EPI == EPI_RS_BIAS_ACT) {
-                        const float rs = a.rowstat ? a.rowstat[m] : 1.f;
-                        v = rs * x + bias;
+                        v = r0[reg] * x + bias;
                         if (a.act == 1) v = silu_f(v);
                         else if (a.act == 2) v = sigmoid_f(v);
                     } else if constexpr (EPI == EPI_NORM) {
-                        float mu = mean_b, rs = rstd_b;
-                        if (a.rowstat) { mu = a.rowstat[2 * m]; rs = a.rowstat[2 * m + 1]; }
-                        v = rs * (x - mu * c2) + c1;
-                        if (a.pe) v += a.pe[(long)s * a.N + n];
+                        const float mu = has_rs ? r1[reg] : mean_b, rs = has_rs ? r0[reg] : rstd_b;
+                        v = rs * (x - mu * c2) + c1 + rv[reg];
                     } else if constexpr (EPI == EPI_BIAS_RES) {
-                        v = a.res[m * a.ldr + n] + x + bias;
+                        v = rv[reg] + x + bias;
                     } else if constexpr (EPI == EPI_RELU_MUL) {
                         v = fmaxf(x, 0.f);
-                        if (a.out2) a.out2[m * a.ldo + n] = v;
-                        v *= a.res[m * a.ldr + n];
+                        if (a.out2 && ok[reg] && nok) a.out2[mrow[reg] * a.ldo + n] = v;
+                        v *= rv[reg];
                     } else if constexpr (EPI == EPI_TANH_SIG) {
                         const float y = acc[0][tm][tn + TN / 2][reg];
                         v = tanhf(x + bias) * sigmoid_f(y + bias2);
                     } else {  // EPI_TCN
                         const float y = acc[NSEG - 1][tm][tn][reg];
-                        v = a.res[m * a.ldr + n] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1);
+                        v = rv[reg] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1);
                     }
-                    a.out[m * a.ldo + n] = v;
-                    if (EPI == EPI_NORM && a.out2) a.out2[m * a.ldo + n] = v;
+                    if (ok[reg] && nok) {
+                        a.out[mrow[reg] * a.ldo + n] = v;
+                        if (EPI == EPI_NORM && a.out2) a.out2[mrow[reg] * a.ldo + n] = v;
+                    }
                 }
             }
         }
@@ -245,6 +331,9 @@ struct ProjNT {
 // ---------------------------------------------------------------------------
 // Quadratic attention scores of one 256-frame group:
 //   P[z, i, j] = relu(q_i . k_j)^2,  q pre-scaled by 1/group.  grid = (2, 2, B*G)
+// Rows past the end of the utterance are computed from clamped (finite) rows:
+// such P rows are never read back, and such P columns only ever multiply value
+// rows that AttnOut zeroes.
 // ---------------------------------------------------------------------------
 struct SimArgs {
     const float* q;  const float* k;   // [B*S][128]
@@ -263,12 +352,11 @@ struct AttnSim {
     }
     __device__ int nk(int) const { return MSF2_QK_DIM / BK; }
     __device__ float4 row(const float* p, int i, int k) const {
-        const int s = g * MSF2_GROUP + i;
-        if (s >= a.S) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(p + ((long)b * a.S + s) * MSF2_QK_DIM + k);
+        const int s = min(g * MSF2_GROUP + i, a.S - 1);
+        return ld4(p + ((long)b * a.S + s) * MSF2_QK_DIM + k);
     }
-    __device__ float4 fetchA(int, int r, int k) const { return row(a.q, m0 + r, k); }
-    __device__ float4 fetchB(int, int c, int k) const { return row(a.k, n0 + c, k); }
+    __device__ float4 fetchA(int, int kt, int r, int ko) const { return row(a.q, m0 + r, kt * BK + ko); }
+    __device__ float4 fetchB(int, int kt, int c, int ko) const { return row(a.k, n0 + c, kt * BK + ko); }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
         float* P = a.P + (long)blockIdx.z * MSF2_GROUP * MSF2_GROUP;
@@ -290,6 +378,7 @@ struct AttnSim {
 // Linear-attention key/value summary, split over time:
 //   part[b, sp, d, e] = sum_{s in chunk sp} lin_k[b, s, d] * hu[b, s, e]
 // grid = (N / 128, nsplit, B); reduced and scaled by 1/S in kv_finalize_kernel.
+// N must be a multiple of 128.
 // ---------------------------------------------------------------------------
 struct LinKVArgs {
     const float* lk;                 // [B*S][128]
@@ -310,15 +399,15 @@ struct LinKV {
         n0 = blockIdx.x * BN;
     }
     __device__ int nk(int) const { return (k1 - k0 + BK - 1) / BK; }
-    __device__ float4 fetchA(int, int r, int k) const {
-        const int s = k0 + k;
-        if (s >= k1) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(a.lk + ((long)b * a.S + s) * MSF2_QK_DIM + r);
+    __device__ float4 fetchA(int, int kt, int r, int ko) const {
+        const int s = k0 + kt * BK + ko;
+        const float m = s < k1 ? 1.f : 0.f;
+        return mul4(ld4(a.lk + ((long)b * a.S + min(s, k1 - 1)) * MSF2_QK_DIM + r), m);
     }
-    __device__ float4 fetchB(int, int c, int k) const {
-        const int s = k0 + k;
-        if (s >= k1 || n0 + c >= a.N) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(a.hu + ((long)b * a.S + s) * a.ldhu + n0 + c);
+    __device__ float4 fetchB(int, int kt, int c, int ko) const {
+        const int s = k0 + kt * BK + ko;
+        const float m = s < k1 ? 1.f : 0.f;
+        return mul4(ld4(a.hu + ((long)b * a.S + min(s, k1 - 1)) * a.ldhu + n0 + c), m);
     }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
@@ -331,7 +420,7 @@ struct LinKV {
                 for (int reg = 0; reg < 16; ++reg) {
                     const int d = MSF2_ACC_ROW(wr, TM, tm, reg, lane);
                     const int e = n0 + MSF2_ACC_COL(wc, TN, tn, lane);
-                    if (e < a.N) out[(long)d * a.N + e] = acc[0][tm][tn][reg];
+                    out[(long)d * a.N + e] = acc[0][tm][tn][reg];
                 }
     }
 };
@@ -354,6 +443,7 @@ struct AttnOutArgs {
 struct AttnOut {
     typedef AttnOutArgs Args;
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
+    static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
     int b, g, m0, j0;
     __device__ void init(const Args& args) {
@@ -362,39 +452,49 @@ struct AttnOut {
         m0 = blockIdx.y * BM;  j0 = blockIdx.x * (BN / 2);
     }
     __device__ int nk(int) const { return (MSF2_GROUP + MSF2_QK_DIM) / BK; }
-    __device__ float4 fetchA(int, int r, int k) const {
+    __device__ float4 fetchA(int, int kt, int r, int ko) const {
         const int i = m0 + r;
-        if (k < MSF2_GROUP)
-            return *reinterpret_cast<const float4*>(a.P + ((long)blockIdx.z * MSF2_GROUP + i) * MSF2_GROUP + k);
-        const int s = g * MSF2_GROUP + i;
-        if (s >= a.S) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + (k - MSF2_GROUP));
+        const float* pq = a.P + ((long)blockIdx.z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
+        const int s = min(g * MSF2_GROUP + i, a.S - 1);
+        const float* pl = a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
+        return ld4(kt < KT_QUAD ? pq : pl);          // kt is wave-uniform: a pointer select, one load
     }
-    __device__ float4 fetchB(int, int c, int k) const {
+    __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
-        if (k < MSF2_GROUP) {
-            const int s = g * MSF2_GROUP + k;
-            if (s >= a.S) return make_float4(0.f, 0.f, 0.f, 0.f);
-            return *reinterpret_cast<const float4*>(a.hu + ((long)b * a.S + s) * a.ldhu + e);
-        }
-        return *reinterpret_cast<const float4*>(a.kv + ((long)b * MSF2_QK_DIM + (k - MSF2_GROUP)) * (2 * a.E) + e);
+        const int s = g * MSF2_GROUP + kt * BK + ko;
+        const float* pq = a.hu + ((long)b * a.S + min(s, a.S - 1)) * a.ldhu + e;
+        const float* pl = a.kv + ((long)b * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko) * (2 * a.E) + e;
+        const float m = (kt < KT_QUAD && s >= a.S) ? 0.f : 1.f;   // value rows past the utterance end are zero
+        return mul4(ld4(kt < KT_QUAD ? pq : pl), m);
     }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+            long mrow[16];
+            bool ok[16];
 #pragma unroll
-            for (int tn = 0; tn < TN / 2; ++tn)
+            for (int reg = 0; reg < 16; ++reg) {
+                const int s = g * MSF2_GROUP + m0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
+                ok[reg] = s < a.S;
+                mrow[reg] = (long)b * a.S + min(s, a.S - 1);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN / 2; ++tn) {
+                const int j = j0 + MSF2_ACC_COL(wc, TN, tn, lane);
+                float v[16], u[16];
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int s = g * MSF2_GROUP + m0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
-                    if (s >= a.S) continue;
-                    const int j = j0 + MSF2_ACC_COL(wc, TN, tn, lane);
-                    const long m = (long)b * a.S + s;
-                    const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
-                    const float v = a.hu[m * a.ldhu + j], u = a.hu[m * a.ldhu + a.E + j];
-                    a.o[m * a.E + j] = (au * v) * sigmoid_f(av * u);
+                    v[reg] = a.hu[mrow[reg] * a.ldhu + j];
+                    u[reg] = a.hu[mrow[reg] * a.ldhu + a.E + j];
                 }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
+                    if (ok[reg]) a.o[mrow[reg] * a.E + j] = (au * v[reg]) * sigmoid_f(av * u[reg]);
+                }
+            }
+        }
     }
 };
 
