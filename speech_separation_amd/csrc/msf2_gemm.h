@@ -215,9 +215,17 @@ struct ProjNT {
     int b, s0, n0;
     __device__ void init(const Args& args) {
         a = args;
-        b = blockIdx.z;
-        s0 = blockIdx.y * BM;
-        n0 = blockIdx.x * (PAIRED ? BN / 2 : BN);
+        // Workgroups are dealt round-robin over the 8 XCDs (one L2 each): remap the
+        // dispatch index so that the column tiles of one row tile -- which re-read the
+        // same A rows -- are consecutive on ONE XCD.  Bijective for any grid size.
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const unsigned nt = t % gridDim.x, rest = t / gridDim.x;
+        b = rest / gridDim.y;
+        s0 = (rest % gridDim.y) * BM;
+        n0 = nt * (PAIRED ? BN / 2 : BN);
     }
     __device__ int nk(int) const { return a.K / BK; }
     // rows past the end of the utterance are clamped (their outputs are never stored)
