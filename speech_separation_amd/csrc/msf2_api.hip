@@ -11,6 +11,8 @@ thread_local int g_last_hip_error = 0;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dim_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+// the kernels address activation buffers with 32-bit byte offsets: rows * row pitch * 4 must stay below 4 GiB
+static inline bool fits32(long rows, long ld) { return rows * ld * 4 < (1L << 32); }
 
 constexpr int ENC_TS = 32;    // frames per block in the encoder / TCN stage A kernels
 constexpr int TCN_TS = 32;
@@ -139,14 +141,15 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_lay
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
         a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
         a.bstat = w.bstat; a.res = h; a.ldr = C;
+        if (j == MSF2_TCN_DEPTH - 1) a.gmul = w.g;     // the last block hands g * h to proj_out
         launch_proj<A_PLAIN, EPI_TCN>(c, a);
         float* tmp = h; h = hn; hn = tmp;
     }
     // x += (g * h) Wpo^T + b
     {
-        ProjArgs a = proj_args(w.g, C, lw.w_po, C, C, c.S, x, C);
-        a.A2 = h; a.bias = lw.b_po; a.res = x; a.ldr = C;
-        launch_proj<A_MUL, EPI_BIAS_RES>(c, a);
+        ProjArgs a = proj_args(h, C, lw.w_po, C, C, c.S, x, C);
+        a.bias = lw.b_po; a.res = x; a.ldr = C;
+        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
     }
 }
 
@@ -161,7 +164,7 @@ static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, floa
 
 // ---- whole forward ----------------------------------------------------------
 struct FwdWs {
-    float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv;
+    float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv, *zeros;
     AttnWs at;
     TcnWs tc;
     int nblk_enc, nblk_ln;
@@ -185,6 +188,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.bstat = ar.take<float>(2L * B);
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
+    w.zeros = ar.take<float>(64);
     w.at = attn_ws(ar, B, S, E);
     w.tc = tcn_ws(ar, B, S, C);
     return w;
@@ -232,6 +236,7 @@ int msf2_num_frames(int T) { return T < 16 ? 0 : (T - 16) / 8 + 1; }
 
 size_t msf2_workspace_bytes(const msf2_config* cfg, int B, int T) {
     if (check_cfg(cfg) != MSF2_OK || B < 1 || T < 16) return 0;
+    if (!fits32((long)B * msf2_num_frames(T), 4 * cfg->dim + MSF2_QK_DIM)) return 0;
     Arena ar(nullptr, 0);
     fwd_ws(ar, *cfg, B, msf2_num_frames(T));
     return ar.off;
@@ -243,6 +248,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     if (rc != MSF2_OK) return rc;
     if (!wt || !mix || !out || !workspace || B < 1 || T < 16 || (cfg->num_layers > 0 && !wt->layers)) return MSF2_ERR_ARG;
     const int C = cfg->dim, E = 2 * C, NH = 4 * C + MSF2_QK_DIM, S = msf2_num_frames(T);
+    if (!fits32((long)B * S, NH)) return MSF2_ERR_ARG;
     Arena ar(workspace, workspace_bytes);
     FwdWs w = fwd_ws(ar, *cfg, B, S);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
@@ -251,6 +257,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     msf2_taps tp = {};
     if (taps) tp = *taps;
 
+    hipMemsetAsync(w.zeros, 0, 256, c.st);   // zero operand rows for the token shift at frame 0
     // encoder + statistics for the mask net's GroupNorm(1, C, eps 1e-8)
     hipLaunchKernelGGL(encoder_kernel, dim3(w.nblk_enc, B), dim3(256), 0, c.st, mix, wt->enc_w, w.enc, w.part, T, S, C, ENC_TS);
     launch_stats_finalize(c, w.part, w.nblk_enc, (long)S * C, 1e-8f, w.bstat);
@@ -269,7 +276,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         launch_rowstat<0>(c, w.x, C, w.rowstat, C, 1, 0.f);
         {   // [v | u | qk] = silu(ScaleNorm(shift(x)) W^T + b)
             ProjArgs a = proj_args(w.x, C, lw.w_hq, C, NH, S, w.hu_pre, NH);
-            a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1;
+            a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1; a.zeros = w.zeros;
             launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
         }
         launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
@@ -343,19 +350,26 @@ int msf2_dwconv17(const float* x, int ldx, const float* dw, float* y, int ldy, i
     return check_launch();
 }
 
-size_t msf2_linear_ws_bytes(int B, int S) { return align_up((size_t)B * S * sizeof(float)); }
+size_t msf2_linear_ws_bytes(int B, int S) { return align_up((size_t)B * S * sizeof(float)) + 256; }
 
 int msf2_linear(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int B, int S, int K, int N,
                 int shift, int scale_norm, int act, int precision, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !W || !y || B < 1 || S < 1 || K < BK || (K % BK) || K > 1024 || N < 1 || ldx < K || ldy < N || (ldx & 3)) return MSF2_ERR_ARG;
     if (precision != MSF2_PREC_FP32 || act < 0 || act > 2) return MSF2_ERR_ARG;
+    if (!fits32((long)B * S, ldx > ldy ? ldx : ldy)) return MSF2_ERR_ARG;
     Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
     ProjArgs a = proj_args(x, ldx, W, K, N, S, y, ldy);
     a.bias = b; a.act = act;
-    if (scale_norm) {
+    if (scale_norm || shift) {
         if (!ws || ws_bytes < msf2_linear_ws_bytes(B, S)) return MSF2_ERR_WORKSPACE;
+    }
+    if (scale_norm) {
         launch_rowstat<0>(c, x, ldx, (float*)ws, K, shift, 0.f);
         a.rowstat = (float*)ws;
+    }
+    if (shift) {
+        a.zeros = (float*)((char*)ws + align_up((size_t)B * S * sizeof(float)));
+        hipMemsetAsync((void*)a.zeros, 0, 256, c.st);
     }
     if (shift) launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
     else launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
@@ -373,7 +387,7 @@ int msf2_flash_attention(const float* hu, int ldhu, const float* os_gamma, const
     if (!hu || !os_gamma || !os_beta || !rot_freqs || !o || !ws || B < 1 || S < 1 || E < 128 || (E % 64) ||
         ldhu < 2 * E + MSF2_QK_DIM || (ldhu & 3))
         return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, ldhu)) return MSF2_ERR_ARG;
     Arena ar(ws, ws_bytes);
     AttnWs w = attn_ws(ar, B, S, E);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
@@ -391,7 +405,7 @@ size_t msf2_gated_tcn_ws_bytes(int B, int S, int C) {
 int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, int precision, void* ws, size_t ws_bytes,
                    void* stream) {
     if (!x || !lw || !ws || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
     Arena ar(ws, ws_bytes);
     TcnWs w = tcn_ws(ar, B, S, C);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
@@ -403,7 +417,7 @@ int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, 
 int msf2_tcn_pointwise(const float* h, const float* t, const float* bstat, const msf2_tcn_weights* tw, float* h_out,
                        int B, int S, int C, int precision, void* stream) {
     if (!h || !t || !bstat || !tw || !h_out || h == h_out || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
     Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
     ProjArgs a = proj_args(h, C, tw->w_gate, C, C, S, h_out, C);
     a.A2 = t; a.W2 = tw->w_pw; a.bias = tw->b_gate; a.c1 = tw->c1; a.c2 = tw->c2;
@@ -411,6 +425,16 @@ int msf2_tcn_pointwise(const float* h, const float* t, const float* bstat, const
     launch_proj<A_PLAIN, EPI_TCN>(c, a);
     return check_launch();
 }
+
+#ifdef MSF2_DIAG_STAMP
+// timing-only build: copy out the per-wave cycle sums of the last contraction launch
+int msf2_diag_read(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(msf2::g_stamp), n * sizeof(unsigned long long));
+}
+int msf2_diag_read2(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(msf2::g_stamp2), n * sizeof(unsigned long long));
+}
+#endif
 
 size_t msf2_decoder_ws_bytes(int B, int S) { return align_up((size_t)B * S * 16 * sizeof(float)); }
 

@@ -1,30 +1,32 @@
 // fp32 contraction kernels on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
 //
 // One kernel template, gemm_kernel<P>, parameterised by a "problem" class P
-// that knows where the operand tiles live (fetchA/fetchB) and what to do with
-// the accumulators (epilogue).  Block tile 128x128, K step 32, 256 threads =
+// that knows where the operand tiles live and what to do with the
+// accumulators (epilogue).  Block tile 128x128, K step 32, 256 threads =
 // 4 waves; each wave owns a 64x64 (2x2 waves) or 32x128 (4x1 waves) sub-tile
-// as 32x32 MFMA accumulators.  Operand tiles are staged global -> registers ->
-// LDS (double buffered, one barrier per K step).
+// as 32x32 MFMA accumulators; 2 blocks per CU; LDS double buffered, one
+// barrier per K step.
 //
-// LDS image and k order.  The MFMA takes one fp32 per lane per operand: lane
-// l supplies row (l & 31) at k index (l >> 5).  The sum over k does not care
-// about order as long as A and B agree, so within each chunk of 8 k values
-// the lower lane half takes k = 0..3 and the upper half k = 4..7, one per
-// MFMA: a lane then needs 4 CONSECUTIVE k of its row per chunk, i.e. one
-// ds_read_b128 per operand tile per 4 MFMA steps from a row-major image
-// [row][32 + 4 pad] (pitch 36 floats: the 16 rows of a ds_read_b128 lane group
-// fall on 16 distinct 16-byte slots of the 256-byte bank row).  Operands that
-// are row-contiguous in global memory (time-major sources) keep a k-major
-// image [k][128 + 4] and read the same k order with four ds_read_b32.
-// Fragments of chunk c+1 are read while the MFMAs of chunk c issue.
+// k order.  The MFMA takes one fp32 per lane per operand: lane l supplies row
+// (l & 31) at k index (l >> 5).  The sum over k does not care about order as
+// long as A and B agree, so within each chunk of 8 k values the lower lane
+// half takes k = 0..3 and the upper half k = 4..7, one per MFMA: a lane then
+// needs 4 CONSECUTIVE k of its row per chunk = one ds_read_b128 per operand
+// tile per 4 MFMA steps.
 //
-// Operand fetches are UNCONDITIONAL loads from clamped addresses; where a zero
-// is semantically required (token shift at frame 0, time steps past the end of
-// a split, key rows past the end of an utterance) the loaded value is
-// multiplied by a 0/1 mask.  Predicated loads with a zero-filled default make
-// hipcc wait for the load inside the fetch sequence, which exposes the whole
-// memory latency once per K step.
+// Staging.  Operands that are k-contiguous in global memory (activations
+// [M][K], weights [N][K], attention scores) go global -> LDS directly
+// (global_load_lds_dwordx4, no VGPRs, no ds_write): one wave instruction moves
+// 8 rows x 128 B into 1 KiB of LDS, lane-linear, so the image is unpadded
+// [128 rows][8 x 16 B] and the bank-conflict swizzle is applied to the SOURCE
+// address: 16-byte chunk c of row r is stored at chunk position
+// c ^ ((r >> 1) & 7); a ds_read_b128 lane group (16 rows, same logical chunk)
+// then covers 16 distinct 16-byte slots of the 256-byte bank row.  Where the
+// reference needs a zero operand (token shift at frame 0) the source address
+// points at a zero buffer.  Operands that are row-contiguous in global memory
+// (time-major sources of the attention summaries) are staged through registers
+// into a k-major image [k][128 + 4] with unconditional clamped loads and a
+// 0/1 mask multiply (predicated loads make hipcc wait inside the fetch).
 #pragma once
 #include "msf2_common.h"
 
@@ -33,65 +35,97 @@ namespace msf2 {
 constexpr int BM = 128, BN = 128, BK = 32;
 enum { ORI_KC = 0, ORI_RC = 1 };   // operand tile is k-contiguous / row-contiguous in global memory
 template <int ORI> struct LdsTile {
-    static constexpr int PITCH = (ORI == ORI_KC) ? (BK + 4) : (BM + 4);
-    static constexpr int SIZE = (ORI == ORI_KC) ? BM * (BK + 4) : BK * (BM + 4);   // floats
+    static constexpr int SIZE = (ORI == ORI_KC) ? BM * BK : BK * (BM + 4);   // floats
 };
+constexpr int RC_PITCH = BM + 4;
 
-template <int ORI>
-__device__ __forceinline__ void tile_coords(int tid, int i, int& r, int& k) {
-    const int e = tid + 256 * i;            // 1024 float4 per 128x32 tile, 4 per thread
-    if (ORI == ORI_KC) { r = e >> 3; k = (e & 7) * 4; }     // float4 along k
-    else               { k = e >> 5; r = (e & 31) * 4; }    // float4 along rows
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
+__device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+__device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+// uniform base + 32-bit byte offset: lowers to the saddr + voffset form of global_load / global_store
+__device__ __forceinline__ float ldg_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg_off(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-template <int ORI>
-__device__ __forceinline__ void lds_put(float* s, int tid, int i, const float4& v) {
-    int r, k;
-    tile_coords<ORI>(tid, i, r, k);
-    constexpr int LD = LdsTile<ORI>::PITCH;
-    if (ORI == ORI_KC) *reinterpret_cast<float4*>(&s[r * LD + k]) = v;
-    else               *reinterpret_cast<float4*>(&s[k * LD + r]) = v;
+// ---- k-contiguous operand: 16 KiB tile = 16 wave-level DMA instructions, 4 per wave
+template <class P, int SEG, bool IS_A>
+__device__ __forceinline__ void dma_tile(const P& prob, float* tile, int kt, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wave * 4 + i;
+        const int row = inst * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ kc_swz(row);          // logical chunk stored at position lane & 7
+        const float* src;
+        if constexpr (IS_A) src = prob.ptrA(SEG, kt, row, chunk * 4);
+        else src = prob.ptrB(SEG, kt, row, chunk * 4);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + inst * 256), 16, 0, 0);
+    }
+}
+
+// ---- row-contiguous operand: float4 along rows, 4 per thread
+__device__ __forceinline__ void rc_coords(int tid, int i, int& r, int& k) {
+    const int e = tid + 256 * i;
+    k = e >> 5;
+    r = (e & 31) * 4;
 }
 
 // the 4 operand values lane (row, kh) feeds to the 4 MFMA steps of chunk c
 template <int ORI>
 __device__ __forceinline__ float4 frag_read(const float* s, int row, int c, int kh) {
-    constexpr int LD = LdsTile<ORI>::PITCH;
+    if (ORI == ORI_KC) return *reinterpret_cast<const float4*>(&s[row * BK + (((2 * c + kh) ^ kc_swz(row)) << 2)]);
     const int k = c * 8 + kh * 4;
-    if (ORI == ORI_KC) return *reinterpret_cast<const float4*>(&s[row * LD + k]);
-    return make_float4(s[(k + 0) * LD + row], s[(k + 1) * LD + row], s[(k + 2) * LD + row], s[(k + 3) * LD + row]);
+    return make_float4(s[(k + 0) * RC_PITCH + row], s[(k + 1) * RC_PITCH + row], s[(k + 2) * RC_PITCH + row],
+                       s[(k + 3) * RC_PITCH + row]);
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
-__device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+#ifdef MSF2_DIAG_STAMP
+__device__ unsigned long long g_stamp[2048 * 4 * 4];
+__device__ unsigned long long g_stamp2[2048 * 4 * 2];
+#define MSF2_STAMP(x) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MSF2_STAMP(x)
+#endif
 
 template <class P, int SEG, int TM, int TN>
 __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* smB,
-                                            f32x16 (&acc)[TM][TN], int tid, int lane, int wr, int wc) {
+                                            f32x16 (&acc)[TM][TN], int tid, int lane, int wave, int wr, int wc) {
     constexpr int SZA = LdsTile<P::A_ORI>::SIZE, SZB = LdsTile<P::B_ORI>::SIZE;
+    constexpr bool A_DMA = P::A_ORI == ORI_KC, B_DMA = P::B_ORI == ORI_KC;
     const int nk = prob.nk(SEG);
-    float4 ra[4], rb[4];
-    auto fetch = [&](int kt) {
+    float4 ra[A_DMA ? 1 : 4], rb[B_DMA ? 1 : 4];
+    auto stage = [&](int kt, int buf) {       // issue the global reads of tile kt
+        if constexpr (A_DMA) dma_tile<P, SEG, true>(prob, smA + buf * SZA, kt, wave, lane);
+        else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r, k;
-            tile_coords<P::A_ORI>(tid, i, r, k);
-            ra[i] = prob.fetchA(SEG, kt, r, k);
-            tile_coords<P::B_ORI>(tid, i, r, k);
-            rb[i] = prob.fetchB(SEG, kt, r, k);
+            for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); ra[i] = prob.fetchA(SEG, kt, r, k); }
+        }
+        if constexpr (B_DMA) dma_tile<P, SEG, false>(prob, smB + buf * SZB, kt, wave, lane);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); rb[i] = prob.fetchB(SEG, kt, r, k); }
         }
     };
-    auto put = [&](int buf) {
+    auto land = [&](int buf) {                // make tile data visible in LDS buffer buf
+        if constexpr (!A_DMA) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lds_put<P::A_ORI>(smA + buf * SZA, tid, i, ra[i]);
-            lds_put<P::B_ORI>(smB + buf * SZB, tid, i, rb[i]);
+            for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); *reinterpret_cast<float4*>(&smA[buf * SZA + k * RC_PITCH + r]) = ra[i]; }
         }
+        if constexpr (!B_DMA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); *reinterpret_cast<float4*>(&smB[buf * SZB + k * RC_PITCH + r]) = rb[i]; }
+        }
+        if constexpr (A_DMA || B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
-    fetch(0);
-    put(0);
-    __syncthreads();
+    stage(0, 0);
+    land(0);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
     auto compute = [&](int cur) {
@@ -104,7 +138,7 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
         for (int t = 0; t < TN; ++t) bf[0][t] = frag_read<P::B_ORI>(sb, rowB + t * 32, 0, kh);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
-            if (c + 1 < BK / 8) {
+            if (c + 1 < BK / 8) {     // fragments of chunk c+1 are read while the MFMAs of chunk c issue
 #pragma unroll
                 for (int t = 0; t < TM; ++t) af[(c + 1) & 1][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, c + 1, kh);
 #pragma unroll
@@ -120,32 +154,53 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
                                                                            acc[tm][tn], 0, 0, 0);
         }
     };
-    // steady state has no conditional around fetch/put (a conditional makes hipcc
-    // merge register assignments with moves that wait on the loads); last tile peeled
+    // steady state is branch-free (a conditional around the staging makes hipcc merge
+    // register assignments with moves that wait on the loads); the last tile is peeled
+#ifdef MSF2_DIAG_STAMP
+    unsigned long long t_stage = 0, t_comp = 0, t_land = 0;
+#endif
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int cur = kt & 1;
-#ifndef MSF2_DIAG_NOFETCH
-        fetch(kt + 1);
+#ifdef MSF2_DIAG_STAMP
+        unsigned long long s0_, s1_, s2_, s3_;
 #endif
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs that hide their latency
+        MSF2_STAMP(s0_)
+        stage(kt + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that hide their latency
+        MSF2_STAMP(s1_)
         compute(cur);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef MSF2_DIAG_NOPUT
-        put(cur ^ 1);
+        MSF2_STAMP(s2_)
+        land(cur ^ 1);
+        MSF2_STAMP(s3_)
+#ifdef MSF2_DIAG_STAMP
+        t_stage += s1_ - s0_; t_comp += s2_ - s1_; t_land += s3_ - s2_;
 #endif
-        __syncthreads();
     }
+#ifdef MSF2_DIAG_STAMP
+    if (lane == 0 && SEG == 0) {
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (L < 2048) {
+            g_stamp[(L * 4 + wave) * 4 + 0] = t_stage; g_stamp[(L * 4 + wave) * 4 + 1] = t_comp;
+            g_stamp[(L * 4 + wave) * 4 + 2] = t_land;  g_stamp[(L * 4 + wave) * 4 + 3] = nk - 1;
+        }
+    }
+#endif
     compute((nk - 1) & 1);
     __syncthreads();
 }
 
 template <class P>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args args) {
-    __shared__ __attribute__((aligned(16))) float smA[2 * LdsTile<P::A_ORI>::SIZE];
-    __shared__ __attribute__((aligned(16))) float smB[2 * LdsTile<P::B_ORI>::SIZE];
+    __shared__ __attribute__((aligned(1024))) float smA[2 * LdsTile<P::A_ORI>::SIZE];
+    __shared__ __attribute__((aligned(1024))) float smB[2 * LdsTile<P::B_ORI>::SIZE];
+#ifdef MSF2_DIAG_STAMP
+    unsigned long long tk0, tk1, tk2;
+    MSF2_STAMP(tk0)
+#endif
     P prob;
     prob.init(args);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / P::WC, wc = wave % P::WC;
     constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
     f32x16 acc[P::NSEG][TM][TN];
@@ -157,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
-    run_segment<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wr, wc);
-    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wr, wc);
+    run_segment<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wave, wr, wc);
+    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wave, wr, wc);
 #ifdef MSF2_DIAG_NOEPI
     {   // timing-only build: keep the accumulators alive with one store per thread
         float sum = 0.f;
@@ -169,8 +224,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
         if (sum == 123.456f) *reinterpret_cast<float*>(smA) = sum;
     }
 #else
-    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+#ifdef MSF2_DIAG_STAMP
+    MSF2_STAMP(tk1)
 #endif
+    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+#ifdef MSF2_DIAG_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MSF2_STAMP(tk2)
+    if (lane == 0) {
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (L < 2048) { g_stamp2[(L * 4 + wave) * 2 + 0] = tk1 - tk0; g_stamp2[(L * 4 + wave) * 2 + 1] = tk2 - tk1; }
+    }
+#endif
+#endif
+}
+
+// XCD-aware, bijective remap of the dispatch index: workgroups are dealt round-robin
+// over the 8 XCDs (one L2 each); after the remap, tiles with consecutive logical ids
+// run consecutively on ONE XCD, so tiles that re-read the same operand rows hit its L2.
+__device__ __forceinline__ unsigned xcd_remap() {
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 // tile-local coordinates of accumulator register `reg` of MFMA tile (tm, tn)
@@ -181,14 +257,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
 // Projections: out[b, s, n] = epilogue( sum_k A'[b, s, k] * W[n, k] )
 // grid = (n tiles, ceil(S / 128), B)
 // ---------------------------------------------------------------------------
-enum { A_PLAIN = 0, A_SHIFT = 1, A_MUL = 2 };
+enum { A_PLAIN = 0, A_SHIFT = 1 };
 enum {
     EPI_RS_BIAS_ACT = 0,  // act(rowscale[m] * acc + bias[n]); act 0 none, 1 SiLU, 2 sigmoid
     EPI_NORM = 1,         // rstd * (acc - mean * c2[n]) + c1[n] (+ pe[s, n]); stats per row or per utterance
     EPI_BIAS_RES = 2,     // res[m, n] + acc + bias[n]
     EPI_RELU_MUL = 3,     // relu(acc) * res[m, n]
     EPI_TANH_SIG = 4,     // paired columns: tanh(accA + bias[n]) * sigmoid(accB + bias2[n])
-    EPI_TCN = 5,          // two accumulators: res + sigmoid(acc0 + bias) * (rstd_b * (acc1 - mean_b * c2) + c1)
+    EPI_TCN = 5,          // two accumulators: (res + sigmoid(acc0 + bias) * (rstd_b * (acc1 - mean_b * c2) + c1)) [* gmul]
 };
 
 struct ProjArgs {
@@ -201,6 +277,8 @@ struct ProjArgs {
     const float* bstat;     // [B][2] (mean, rstd)
     const float* res;  int ldr;
     const float* pe;        // [S][N]
+    const float* gmul;      // EPI_TCN: optional elementwise gate multiplied onto the result, [B*S][ldo]
+    const float* zeros;     // A_SHIFT: >= 128 bytes of zeros
     int act;
 };
 
@@ -215,13 +293,7 @@ struct ProjNT {
     int b, s0, n0;
     __device__ void init(const Args& args) {
         a = args;
-        // Workgroups are dealt round-robin over the 8 XCDs (one L2 each): remap the
-        // dispatch index so that the column tiles of one row tile -- which re-read the
-        // same A rows -- are consecutive on ONE XCD.  Bijective for any grid size.
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned xcd = L & 7, idx = L >> 3, q = total >> 3, r = total & 7;
-        const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const unsigned t = xcd_remap();       // column tiles of one row tile share the A rows
         const unsigned nt = t % gridDim.x, rest = t / gridDim.x;
         b = rest / gridDim.y;
         s0 = (rest % gridDim.y) * BM;
@@ -229,36 +301,32 @@ struct ProjNT {
     }
     __device__ int nk(int) const { return a.K / BK; }
     // rows past the end of the utterance are clamped (their outputs are never stored)
-    __device__ float4 fetchA(int seg, int kt, int r, int ko) const {
+    __device__ const float* ptrA(int seg, int kt, int r, int ko) const {
         const int s = min(s0 + r, a.S - 1);
         const int k = kt * BK + ko;
         long row = (long)b * a.S + s;
         const float* base = (NSEG == 2 && seg == 1) ? a.A2 : a.A;
-        float m = 1.f;
         if (AMODE == A_SHIFT) {
             // first half of the features comes from the previous frame, zero at frame 0
             const bool sh = k < (a.K >> 1);
             row -= (sh && s > 0) ? 1 : 0;
-            m = (sh && s == 0) ? 0.f : 1.f;
+            const float* p = base + row * a.lda + k;
+            return (sh && s == 0) ? a.zeros : p;
         }
-        float4 v = ld4(base + row * a.lda + k);
-        if (AMODE == A_SHIFT) v = mul4(v, m);
-        if (AMODE == A_MUL) {
-            const float4 g = ld4(a.A2 + row * a.lda + k);
-            v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
-        }
-        return v;
+        return base + row * a.lda + k;
     }
-    __device__ float4 fetchB(int seg, int kt, int c, int ko) const {
+    __device__ const float* ptrB(int seg, int kt, int c, int ko) const {
         const float* w = a.W;
         int n = n0 + c;
         if (PAIRED && c >= BN / 2) { n -= BN / 2; w = a.W2; }
         if (NSEG == 2 && seg == 1) w = a.W2;
         n = min(n, a.N - 1);
-        return ld4(w + (long)n * a.K + kt * BK + ko);
+        return w + (long)n * a.K + kt * BK + ko;
     }
-    // Loads are issued in batches of 16 from clamped addresses (no branch between
-    // them), so their latency overlaps; only the stores are predicated.
+    // All loads of the epilogue are issued up front from clamped addresses (no branch
+    // between them), so the tile pays one memory round trip; only stores are predicated.
+    // Addresses are uniform base + 32-bit byte offset (the host rejects shapes whose
+    // buffers exceed 4 GiB), which keeps the address arithmetic out of 64-bit VGPR pairs.
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane) const {
         float mean_b = 0.f, rstd_b = 1.f;
@@ -267,23 +335,36 @@ struct ProjNT {
         constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);
         constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || EPI == EPI_TCN);
         const bool has_rs = a.rowstat != nullptr;
+        const bool has_g = (EPI == EPI_TCN) && a.gmul != nullptr;
+        const unsigned ldr4 = 4u * a.ldr, ldo4 = 4u * a.ldo, m_base = (unsigned)b * a.S;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            long mrow[16];
+            unsigned mrow[16];
             bool ok[16];
             float r0[16], r1[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int s = s0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
                 ok[reg] = s < a.S;
-                mrow[reg] = (long)b * a.S + min(s, a.S - 1);
+                mrow[reg] = m_base + min(s, a.S - 1);
                 r0[reg] = 1.f; r1[reg] = 0.f;
             }
             if (ROWSTAT && has_rs) {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    if (EPI == EPI_RS_BIAS_ACT) r0[reg] = a.rowstat[mrow[reg]];
-                    else { r1[reg] = a.rowstat[2 * mrow[reg]]; r0[reg] = a.rowstat[2 * mrow[reg] + 1]; }
+                    if (EPI == EPI_RS_BIAS_ACT) r0[reg] = ldg_off(a.rowstat, mrow[reg] * 4u);
+                    else { r1[reg] = ldg_off(a.rowstat, mrow[reg] * 8u); r0[reg] = ldg_off(a.rowstat, mrow[reg] * 8u + 4u); }
+                }
+            }
+            float rv[TNE][16];
+#pragma unroll
+            for (int tn = 0; tn < TNE; ++tn) {
+                const unsigned nc4 = 4u * min(n0 + MSF2_ACC_COL(wc, TN, tn, lane), a.N - 1);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = RES ? ldg_off(a.res, mrow[reg] * ldr4 + nc4) : 0.f;
+                if (EPI == EPI_NORM && a.pe) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = ldg_off(a.pe, (mrow[reg] - m_base) * (4u * a.N) + nc4);
                 }
             }
 #pragma unroll
@@ -291,16 +372,17 @@ struct ProjNT {
                 const int n = n0 + MSF2_ACC_COL(wc, TN, tn, lane);
                 const bool nok = n < a.N;
                 const int nc = min(n, a.N - 1);
+                const unsigned nc4 = 4u * nc;
                 const float bias = a.bias ? a.bias[nc] : 0.f;
                 const float bias2 = (EPI == EPI_TANH_SIG) ? a.bias2[nc] : 0.f;
                 const float c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c1[nc] : 0.f;
                 const float c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c2[nc] : 0.f;
-                float rv[16];
+                float gv[16];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) rv[reg] = RES ? a.res[mrow[reg] * a.ldr + nc] : 0.f;
-                if (EPI == EPI_NORM && a.pe) {
+                for (int reg = 0; reg < 16; ++reg) gv[reg] = 1.f;
+                if (has_g) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) rv[reg] = a.pe[(mrow[reg] - (long)b * a.S) * a.N + nc];
+                    for (int reg = 0; reg < 16; ++reg) gv[reg] = ldg_off(a.gmul, mrow[reg] * ldo4 + nc4);
                 }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
@@ -312,23 +394,23 @@ struct ProjNT {
                         else if (a.act == 2) v = sigmoid_f(v);
                     } else if constexpr (EPI == EPI_NORM) {
                         const float mu = has_rs ? r1[reg] : mean_b, rs = has_rs ? r0[reg] : rstd_b;
-                        v = rs * (x - mu * c2) + c1 + rv[reg];
+                        v = rs * (x - mu * c2) + c1 + rv[tn][reg];
                     } else if constexpr (EPI == EPI_BIAS_RES) {
-                        v = rv[reg] + x + bias;
+                        v = rv[tn][reg] + x + bias;
                     } else if constexpr (EPI == EPI_RELU_MUL) {
                         v = fmaxf(x, 0.f);
-                        if (a.out2 && ok[reg] && nok) a.out2[mrow[reg] * a.ldo + n] = v;
-                        v *= rv[reg];
+                        if (a.out2 && ok[reg] && nok) stg_off(a.out2, mrow[reg] * ldo4 + nc4, v);
+                        v *= rv[tn][reg];
                     } else if constexpr (EPI == EPI_TANH_SIG) {
                         const float y = acc[0][tm][tn + TN / 2][reg];
                         v = tanhf(x + bias) * sigmoid_f(y + bias2);
                     } else {  // EPI_TCN
                         const float y = acc[NSEG - 1][tm][tn][reg];
-                        v = rv[reg] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1);
+                        v = (rv[tn][reg] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1)) * gv[reg];
                     }
                     if (ok[reg] && nok) {
-                        a.out[mrow[reg] * a.ldo + n] = v;
-                        if (EPI == EPI_NORM && a.out2) a.out2[mrow[reg] * a.ldo + n] = v;
+                        stg_off(a.out, mrow[reg] * ldo4 + nc4, v);
+                        if (EPI == EPI_NORM && a.out2) stg_off(a.out2, mrow[reg] * ldo4 + nc4, v);
                     }
                 }
             }
@@ -359,12 +441,12 @@ struct AttnSim {
         m0 = blockIdx.y * BM;  n0 = blockIdx.x * BN;
     }
     __device__ int nk(int) const { return MSF2_QK_DIM / BK; }
-    __device__ float4 row(const float* p, int i, int k) const {
+    __device__ const float* row(const float* p, int i, int k) const {
         const int s = min(g * MSF2_GROUP + i, a.S - 1);
-        return ld4(p + ((long)b * a.S + s) * MSF2_QK_DIM + k);
+        return p + ((long)b * a.S + s) * MSF2_QK_DIM + k;
     }
-    __device__ float4 fetchA(int, int kt, int r, int ko) const { return row(a.q, m0 + r, kt * BK + ko); }
-    __device__ float4 fetchB(int, int kt, int c, int ko) const { return row(a.k, n0 + c, kt * BK + ko); }
+    __device__ const float* ptrA(int, int kt, int r, int ko) const { return row(a.q, m0 + r, kt * BK + ko); }
+    __device__ const float* ptrB(int, int kt, int c, int ko) const { return row(a.k, n0 + c, kt * BK + ko); }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
         float* P = a.P + (long)blockIdx.z * MSF2_GROUP * MSF2_GROUP;
@@ -438,7 +520,7 @@ struct LinKV {
 // value columns (v and u halves side by side in the B tile):
 //   att = [P | lin_q] x [vu rows of the group ; KV],   K = 256 + 128
 //   o[m, j] = (att_u * v[m, j]) * sigmoid(att_v * u[m, j])
-// grid = (E / 64, 2, B*G)
+// grid = (E / 64, 2, B*G), remapped so the column tiles of one half-group share an XCD
 // ---------------------------------------------------------------------------
 struct AttnOutArgs {
     const float* P;                  // [B*G][256][256]
@@ -453,19 +535,22 @@ struct AttnOut {
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
     static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
-    int b, g, m0, j0;
+    int z, b, g, m0, j0;
     __device__ void init(const Args& args) {
         a = args;
-        b = blockIdx.z / a.G;  g = blockIdx.z % a.G;
-        m0 = blockIdx.y * BM;  j0 = blockIdx.x * (BN / 2);
+        const unsigned t = xcd_remap();
+        const unsigned jt = t % gridDim.x, rest = t / gridDim.x;
+        z = rest / gridDim.y;
+        b = z / a.G;  g = z % a.G;
+        m0 = (rest % gridDim.y) * BM;  j0 = jt * (BN / 2);
     }
     __device__ int nk(int) const { return (MSF2_GROUP + MSF2_QK_DIM) / BK; }
-    __device__ float4 fetchA(int, int kt, int r, int ko) const {
+    __device__ const float* ptrA(int, int kt, int r, int ko) const {
         const int i = m0 + r;
-        const float* pq = a.P + ((long)blockIdx.z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
+        const float* pq = a.P + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
         const int s = min(g * MSF2_GROUP + i, a.S - 1);
         const float* pl = a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
-        return ld4(kt < KT_QUAD ? pq : pl);          // kt is wave-uniform: a pointer select, one load
+        return kt < KT_QUAD ? pq : pl;               // kt is wave-uniform
     }
     __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
@@ -477,29 +562,34 @@ struct AttnOut {
     }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
+        const unsigned ldh4 = 4u * a.ldhu, e4 = 4u * a.E;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            long mrow[16];
+            unsigned mrow[16];
             bool ok[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int s = g * MSF2_GROUP + m0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
                 ok[reg] = s < a.S;
-                mrow[reg] = (long)b * a.S + min(s, a.S - 1);
+                mrow[reg] = (unsigned)b * a.S + min(s, a.S - 1);
+            }
+            float v[TN / 2][16], u[TN / 2][16];
+#pragma unroll
+            for (int tn = 0; tn < TN / 2; ++tn) {
+                const unsigned j4 = 4u * (j0 + MSF2_ACC_COL(wc, TN, tn, lane));
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    v[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + j4);
+                    u[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + e4 + j4);
+                }
             }
 #pragma unroll
             for (int tn = 0; tn < TN / 2; ++tn) {
-                const int j = j0 + MSF2_ACC_COL(wc, TN, tn, lane);
-                float v[16], u[16];
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    v[reg] = a.hu[mrow[reg] * a.ldhu + j];
-                    u[reg] = a.hu[mrow[reg] * a.ldhu + a.E + j];
-                }
+                const unsigned j4 = 4u * (j0 + MSF2_ACC_COL(wc, TN, tn, lane));
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
-                    if (ok[reg]) a.o[mrow[reg] * a.E + j] = (au * v[reg]) * sigmoid_f(av * u[reg]);
+                    if (ok[reg]) stg_off(a.o, mrow[reg] * e4 + j4, (au * v[tn][reg]) * sigmoid_f(av * u[tn][reg]));
                 }
             }
         }
