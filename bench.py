@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32: exact fp32 MFMA (the headline configuration); bf16: bf16 MFMA operands, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -89,7 +91,9 @@ def main():
 
     B, T = a.batch, int(round(a.seconds * 8000))
     sd = make_state_dict(cfg, 0)
-    model = MossFormerHIP(cfg, compute_device=dev)
+    from speech_separation_amd import _lib
+    prec = _lib.PREC_BF16 if a.precision == "bf16" else _lib.PREC_FP32
+    model = MossFormerHIP(cfg, compute_device=dev, precision=prec)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.eval()
     x = torch.from_numpy(synth_batch(B, T, seed0=rank * B)).to(dev)
@@ -134,10 +138,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if prec == _lib.PREC_FP32 else "bf16",
         "data": "synthetic",
         "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {a.seconds:g} s Libri2Mix-min-shaped 8 kHz mixtures, "
-                               "fp32, random-init weights (seeded recipe)",
+                               f"{a.precision}, random-init weights (seeded recipe)",
                    "batch_per_gpu": B, "samples": T, "layers": cfg.num_layers, "dim": cfg.dim,
                    "parallelism": f"utterance-sharded x{world}"},
         "model_tflops_per_s": world * B * cfg.flops(T) * a.steps / dt / 1e12,
@@ -145,11 +149,20 @@ def main():
 
     if rank == 0:
         ms, flops = dominant_kernel_probe(model, B, T)
-        peak = 157.3
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
-                           "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                           "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
-                           "launch_ms": ms}
+        if prec == _lib.PREC_FP32:
+            peak = 157.3
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
+                               "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                               "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
+                               "launch_ms": ms}
+        else:
+            # at bf16 MFMA rates the same kernel is bandwidth bound: it must read h and t and write h' once
+            S_ = model.cfg.frames(T)
+            gbytes = 3.0 * B * S_ * cfg.dim * 4 / 1e9
+            res["roofline"] = {"bound": "hbm", "kernel": "gemm_kernel_bf16<ProjNT<0,5>> (TCN pointwise, bf16 MFMA 32x32x16)",
+                               "achieved": gbytes / (ms * 1e-3), "peak": 8000.0, "unit": "GB/s",
+                               "frac": gbytes / (ms * 1e-3) / 8000.0, "traffic": None, "launch_ms": ms,
+                               "tflops": flops / (ms * 1e-3) / 1e12}
         if not a.no_cpu_baseline and world == 1:
             from oracle import cpu_ref           # the CPU port that is timed, never the product path
             cores = min(os.cpu_count() or 1, 16)

@@ -50,7 +50,10 @@ typedef struct msf2_config {
 } msf2_config;
 
 /*
- * Packed weights.  All arrays fp32, device resident, written once by the host
+ * Packed weights.  Device resident, written once by the host; fp32, except that
+ * with precision == MSF2_PREC_BF16 the projection matrices (the [N][K] arrays:
+ * w_hq, w_out, w_gg, w_in, w_po, tcn[].w_gate, tcn[].w_pw, w_ce, w_co, w_o,
+ * w_og, w_cd) hold bf16 values.  Layout as written by the host
  * side (speech_separation_amd/packing.py) from a reference state_dict:
  * norm gains are folded into the following projection, depthwise filters are
  * stored tap-major [taps][C].  "c1"/"c2" are the two vectors that move a

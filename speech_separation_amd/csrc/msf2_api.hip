@@ -3,6 +3,7 @@
 // nothing here allocates, synchronises or keeps mutable global state.
 #include "msf2_common.h"
 #include "msf2_gemm.h"
+#include "msf2_gemm_bf16.h"
 #include "msf2_ops.h"
 
 namespace msf2 {
@@ -21,14 +22,22 @@ struct Ctx {
     hipStream_t st;
     int B, S, T;
     long M;
+    int prec = MSF2_PREC_FP32;
 };
+
+// launch the fp32 or the bf16 build of a contraction
+template <class P>
+static void launch_gemm(const Ctx& c, dim3 grid, const typename P::Args& a) {
+    if (c.prec == MSF2_PREC_BF16) hipLaunchKernelGGL(gemm_kernel_bf16<P>, grid, dim3(256), 0, c.st, a);
+    else hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), 0, c.st, a);
+}
 
 // ---- projection launcher ----------------------------------------------------
 template <int AMODE, int EPI>
 static void launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
-    hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), 0, c.st, a);
+    launch_gemm<P>(c, grid, a);
 }
 
 static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N, int S, float* out, int ldo) {
@@ -85,17 +94,17 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
     const float* lin_k = w.q4 + 3 * M * MSF2_QK_DIM;
     {
         LinKVArgs a = {lin_k, hu, ldhu, w.part, c.S, 2 * E, w.chunk};
-        hipLaunchKernelGGL(gemm_kernel<LinKV>, dim3(cdiv(2 * E, BN), w.nsplit, c.B), dim3(256), 0, c.st, a);
+        launch_gemm<LinKV>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
         const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
     }
     {
         SimArgs a = {quad_q, quad_k, w.P, c.S, w.G};
-        hipLaunchKernelGGL(gemm_kernel<AttnSim>, dim3(2, 2, c.B * w.G), dim3(256), 0, c.st, a);
+        launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
     }
     {
         AttnOutArgs a = {w.P, lin_q, hu, ldhu, w.kv, o, c.S, w.G, E};
-        hipLaunchKernelGGL(gemm_kernel<AttnOut>, dim3(E / (BN / 2), 2, c.B * w.G), dim3(256), 0, c.st, a);
+        launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
     }
 }
 
@@ -197,7 +206,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
 static int check_cfg(const msf2_config* cfg) {
     if (!cfg) return MSF2_ERR_ARG;
     if (!dim_ok(cfg->dim) || cfg->num_layers < 0 || cfg->enc_kernel != 16 || cfg->num_spks != 2) return MSF2_ERR_ARG;
-    if (cfg->precision != MSF2_PREC_FP32) return MSF2_ERR_ARG;
+    if (cfg->precision != MSF2_PREC_FP32 && cfg->precision != MSF2_PREC_BF16) return MSF2_ERR_ARG;
     return MSF2_OK;
 }
 
@@ -252,7 +261,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     Arena ar(workspace, workspace_bytes);
     FwdWs w = fwd_ws(ar, *cfg, B, S);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
-    Ctx c = {(hipStream_t)stream, B, S, T, (long)B * S};
+    Ctx c = {(hipStream_t)stream, B, S, T, (long)B * S, cfg->precision};
     const long MC = c.M * C;
     msf2_taps tp = {};
     if (taps) tp = *taps;
@@ -355,9 +364,9 @@ size_t msf2_linear_ws_bytes(int B, int S) { return align_up((size_t)B * S * size
 int msf2_linear(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int B, int S, int K, int N,
                 int shift, int scale_norm, int act, int precision, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !W || !y || B < 1 || S < 1 || K < BK || (K % BK) || K > 1024 || N < 1 || ldx < K || ldy < N || (ldx & 3)) return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32 || act < 0 || act > 2) return MSF2_ERR_ARG;
+    if ((precision != MSF2_PREC_FP32 && precision != MSF2_PREC_BF16) || act < 0 || act > 2) return MSF2_ERR_ARG;
     if (!fits32((long)B * S, ldx > ldy ? ldx : ldy)) return MSF2_ERR_ARG;
-    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
     ProjArgs a = proj_args(x, ldx, W, K, N, S, y, ldy);
     a.bias = b; a.act = act;
     if (scale_norm || shift) {
@@ -387,11 +396,11 @@ int msf2_flash_attention(const float* hu, int ldhu, const float* os_gamma, const
     if (!hu || !os_gamma || !os_beta || !rot_freqs || !o || !ws || B < 1 || S < 1 || E < 128 || (E % 64) ||
         ldhu < 2 * E + MSF2_QK_DIM || (ldhu & 3))
         return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, ldhu)) return MSF2_ERR_ARG;
+    if ((precision != MSF2_PREC_FP32 && precision != MSF2_PREC_BF16) || !fits32((long)B * S, ldhu)) return MSF2_ERR_ARG;
     Arena ar(ws, ws_bytes);
     AttnWs w = attn_ws(ar, B, S, E);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
-    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
     run_attention(c, w, hu, ldhu, os_gamma, os_beta, rot_freqs, o, E);
     return check_launch();
 }
@@ -405,11 +414,11 @@ size_t msf2_gated_tcn_ws_bytes(int B, int S, int C) {
 int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, int precision, void* ws, size_t ws_bytes,
                    void* stream) {
     if (!x || !lw || !ws || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
+    if ((precision != MSF2_PREC_FP32 && precision != MSF2_PREC_BF16) || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
     Arena ar(ws, ws_bytes);
     TcnWs w = tcn_ws(ar, B, S, C);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
-    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
     run_gated_tcn(c, w, x, *lw, C);
     return check_launch();
 }
@@ -417,8 +426,8 @@ int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, 
 int msf2_tcn_pointwise(const float* h, const float* t, const float* bstat, const msf2_tcn_weights* tw, float* h_out,
                        int B, int S, int C, int precision, void* stream) {
     if (!h || !t || !bstat || !tw || !h_out || h == h_out || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
-    if (precision != MSF2_PREC_FP32 || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
-    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    if ((precision != MSF2_PREC_FP32 && precision != MSF2_PREC_BF16) || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
     ProjArgs a = proj_args(h, C, tw->w_gate, C, C, S, h_out, C);
     a.A2 = t; a.W2 = tw->w_pw; a.bias = tw->b_gate; a.c1 = tw->c1; a.c2 = tw->c2;
     a.bstat = bstat; a.res = h; a.ldr = C;

@@ -289,6 +289,7 @@ struct ProjNT {
     static constexpr int WR = PAIRED ? 4 : 2, WC = PAIRED ? 1 : 2;
     static constexpr int NSEG = (EPI == EPI_TCN) ? 2 : 1;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
+    static constexpr bool B_BF16 = true;    // bf16 kernels read W as bf16
     Args a;
     int b, s0, n0;
     __device__ void init(const Args& args) {
@@ -322,6 +323,15 @@ struct ProjNT {
         if (NSEG == 2 && seg == 1) w = a.W2;
         n = min(n, a.N - 1);
         return w + (long)n * a.K + kt * BK + ko;
+    }
+    // bf16 kernels: W / W2 point at bf16 weights [N][K]
+    __device__ const unsigned short* ptrB16(int seg, int kt, int c, int ko) const {
+        const float* w = a.W;
+        int n = n0 + c;
+        if (PAIRED && c >= BN / 2) { n -= BN / 2; w = a.W2; }
+        if (NSEG == 2 && seg == 1) w = a.W2;
+        n = min(n, a.N - 1);
+        return reinterpret_cast<const unsigned short*>(w) + (long)n * a.K + kt * BK + ko;
     }
     // All loads of the epilogue are issued up front from clamped addresses (no branch
     // between them), so the tile pays one memory round trip; only stores are predicated.
@@ -433,6 +443,7 @@ struct SimArgs {
 struct AttnSim {
     typedef SimArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
+    static constexpr bool B_BF16 = false;
     Args a;
     int b, g, m0, n0;
     __device__ void init(const Args& args) {
@@ -479,6 +490,7 @@ struct LinKVArgs {
 struct LinKV {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
+    static constexpr bool B_BF16 = false;
     Args a;
     int b, k0, k1, n0;
     __device__ void init(const Args& args) {
@@ -533,6 +545,7 @@ struct AttnOutArgs {
 struct AttnOut {
     typedef AttnOutArgs Args;
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
+    static constexpr bool B_BF16 = false;
     static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
     int z, b, g, m0, j0;

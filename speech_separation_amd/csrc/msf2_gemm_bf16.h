@@ -1,0 +1,174 @@
+// bf16 contraction kernels (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//
+// Same problem classes, tiling (128x128 block, 4 waves, 32x32 accumulators) and
+// epilogues as the fp32 kernels in msf2_gemm.h -- the accumulator layout of the
+// 32x32 MFMA does not depend on the operand type -- but the operands are bf16:
+//   * activations stay fp32 in HBM (residual stream, statistics and every
+//     elementwise kernel are fp32); they are rounded to bf16 (RNE,
+//     v_cvt_pk_bf16_f32) on their way into LDS;
+//   * projection weights are stored as bf16 by the host-side packing.
+// At bf16 MFMA rates these shapes (K = 512) are bandwidth bound, so the tile
+// loop is kept simple: register staging, K step 32, double-buffered LDS, one
+// barrier per step, 2-3 workgroups per CU for memory-level parallelism.
+//
+// LDS image: [128 rows][32 k] bf16 = 64 B per row, 16-byte chunk c of row r at
+// chunk position c ^ ((r >> 2) & 3): the 16 rows of a ds_read_b128 lane group
+// then cover 16 distinct 16-byte slots of the 256-byte bank row.  An MFMA lane
+// (row, half h) takes the 8 consecutive k = 16*step + 8*h .. +7: one
+// ds_read_b128.  Row-contiguous (time-major) sources are transposed 4x4 in
+// registers on the way in, so every operand ends up in the same image.
+#pragma once
+#include "msf2_gemm.h"
+
+namespace msf2 {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ int bf_swz(int row) { return (row >> 2) & 3; }
+constexpr int BF_TILE = BM * BK * 2;   // bytes of one 128 x 32 bf16 operand tile
+
+enum { SRC_KC_F32 = 0, SRC_KC_BF16 = 1, SRC_RC_F32 = 2 };
+
+template <class P, int SEG, bool IS_A, int SRC>
+__device__ __forceinline__ void bf_fetch(const P& prob, int kt, int tid, float4 (&r)[4]) {
+    if constexpr (SRC == SRC_KC_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            if constexpr (IS_A) r[i] = ld4(prob.ptrA(SEG, kt, e >> 3, (e & 7) * 4));
+            else r[i] = ld4(prob.ptrB(SEG, kt, e >> 3, (e & 7) * 4));
+        }
+    } else if constexpr (SRC == SRC_KC_BF16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i;
+            const uint4 v = *reinterpret_cast<const uint4*>(prob.ptrB16(SEG, kt, e >> 2, (e & 3) * 8));
+            r[i] = __builtin_bit_cast(float4, v);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (IS_A) r[i] = prob.fetchA(SEG, kt, (tid & 31) * 4, (tid >> 5) * 4 + i);
+            else r[i] = prob.fetchB(SEG, kt, (tid & 31) * 4, (tid >> 5) * 4 + i);
+        }
+    }
+}
+
+template <int SRC>
+__device__ __forceinline__ void bf_put(char* tile, int tid, const float4 (&r)[4]) {
+    if constexpr (SRC == SRC_KC_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, row = e >> 3, kq = e & 7;
+            uint2 v;
+            v.x = pk_bf16(r[i].x, r[i].y);
+            v.y = pk_bf16(r[i].z, r[i].w);
+            *reinterpret_cast<uint2*>(tile + row * 64 + (((kq >> 1) ^ bf_swz(row)) << 4) + (kq & 1) * 8) = v;
+        }
+    } else if constexpr (SRC == SRC_KC_BF16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = tid + 256 * i, row = e >> 2, ch = e & 3;
+            *reinterpret_cast<uint4*>(tile + row * 64 + ((ch ^ bf_swz(row)) << 4)) = __builtin_bit_cast(uint4, r[i]);
+        }
+    } else {
+        // r[i] = 4 consecutive rows at k = 4*kq + i: transpose so each row gets its 4 consecutive k
+        const int kq = tid >> 5, nq = tid & 31;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * nq + c;
+            uint2 v;
+            v.x = pk_bf16(f4get(r[0], c), f4get(r[1], c));
+            v.y = pk_bf16(f4get(r[2], c), f4get(r[3], c));
+            *reinterpret_cast<uint2*>(tile + row * 64 + (((kq >> 1) ^ bf_swz(row)) << 4) + (kq & 1) * 8) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8_t bf_frag(const char* tile, int row, int step, int kh) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 64 + (((2 * step + kh) ^ bf_swz(row)) << 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <class P> struct BfSrc {
+    static constexpr int A = (P::A_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32;
+    static constexpr int B = P::B_BF16 ? SRC_KC_BF16 : ((P::B_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32);
+};
+
+template <class P, int SEG, int TM, int TN>
+__device__ __forceinline__ void run_segment_bf16(const P& prob, char* smA, char* smB, f32x16 (&acc)[TM][TN],
+                                                 int tid, int lane, int wr, int wc) {
+    constexpr int SA = BfSrc<P>::A, SB = BfSrc<P>::B;
+    const int nk = prob.nk(SEG);
+    float4 ra[4], rb[4];
+    bf_fetch<P, SEG, true, SA>(prob, 0, tid, ra);
+    bf_fetch<P, SEG, false, SB>(prob, 0, tid, rb);
+    bf_put<SA>(smA, tid, ra);
+    bf_put<SB>(smB, tid, rb);
+    __syncthreads();
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
+    auto compute = [&](int cur) {
+        const char* sa = smA + cur * BF_TILE;
+        const char* sb = smB + cur * BF_TILE;
+        bf16x8_t af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) af[st][t] = bf_frag(sa, rowA + t * 32, st, kh);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bf[st][t] = bf_frag(sb, rowB + t * 32, st, kh);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], acc[tm][tn], 0, 0, 0);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        bf_fetch<P, SEG, true, SA>(prob, kt + 1, tid, ra);
+        bf_fetch<P, SEG, false, SB>(prob, kt + 1, tid, rb);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        bf_put<SA>(smA + (cur ^ 1) * BF_TILE, tid, ra);
+        bf_put<SB>(smB + (cur ^ 1) * BF_TILE, tid, rb);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+    __syncthreads();
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Args args) {
+    __shared__ __attribute__((aligned(16))) char smA[2 * BF_TILE];
+    __shared__ __attribute__((aligned(16))) char smB[2 * BF_TILE];
+    P prob;
+    prob.init(args);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / P::WC, wc = wave % P::WC;
+    constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
+    f32x16 acc[P::NSEG][TM][TN];
+#pragma unroll
+    for (int s = 0; s < P::NSEG; ++s)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
+    run_segment_bf16<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wr, wc);
+    if constexpr (P::NSEG == 2) run_segment_bf16<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wr, wc);
+    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+}
+
+}  // namespace msf2

@@ -57,6 +57,8 @@ def linear(x, W, b=None, shift=False, scale_norm=False, act=0, precision=_lib.PR
     _chk(x, W)
     B, S, K = x.shape
     N = W.shape[0]
+    if precision == _lib.PREC_BF16:          # the bf16 kernels take the weight matrix as bf16
+        W = W.to(torch.bfloat16).contiguous()
     y = torch.empty((B, S, N), device=x.device)
     n = lib.msf2_linear_ws_bytes(B, S)
     ws = _ws(n, x.device)

@@ -28,17 +28,31 @@ class PackedWeights:
         d = cfg.dim
         g = lambda k: state[k].detach().to("cpu", torch.float64)
 
+        bf16 = precision == _lib.PREC_BF16
+
         def dev(t):
             t = t.to(torch.float32).contiguous().to(self.device)
             self._keep.append(t)
             return t.data_ptr()
 
+        def devw(t):
+            """A projection matrix [N, K]: the B operand of a contraction kernel
+            (bf16 in MSF2_PREC_BF16 mode, fp32 otherwise)."""
+            if not bf16:
+                return dev(t)
+            t = t.to(torch.float32).to(torch.bfloat16).contiguous().to(self.device)
+            self._keep.append(t)
+            return t.data_ptr()
+
         def fold_norm(W, b, gain, offset):
-            """norm(x) W^T + b -> (W diag(gain), c1 = W offset + b, c2 = W gain)."""
+            """norm(x) W^T + b -> (W diag(gain), c1 = W offset + b, c2 = W gain).
+            c2 is summed over the weights as the kernel will see them (bf16-rounded in
+            bf16 mode) so that the mean term cancels exactly."""
             Wg = W * gain[None, :]
             c1 = W @ offset + (b if b is not None else 0.0)
-            c2 = Wg.sum(dim=1)
-            return dev(Wg), dev(c1), dev(c2)
+            Wr = Wg.to(torch.float32).to(torch.bfloat16).to(torch.float64) if bf16 else Wg
+            c2 = Wr.sum(dim=1)
+            return devw(Wg), dev(c1), dev(c2)
 
         self.layers = (_lib.LayerWeights * max(cfg.num_layers, 1))()
         for i in range(cfg.num_layers):
@@ -46,7 +60,7 @@ class PackedWeights:
             p = f"{MDL}.layers.{i}"
             Wh = g(f"{p}.to_hidden.mdl.1.weight") * g(f"{p}.to_hidden.mdl.0.g")
             Wq = g(f"{p}.to_qk.mdl.1.weight") * g(f"{p}.to_qk.mdl.0.g")
-            lw.w_hq = dev(torch.cat((Wh, Wq), 0))
+            lw.w_hq = devw(torch.cat((Wh, Wq), 0))
             lw.b_hq = dev(torch.cat((g(f"{p}.to_hidden.mdl.1.bias"), g(f"{p}.to_qk.mdl.1.bias")), 0))
             dwh = g(f"{p}.to_hidden.mdl.3.sequential.1.conv.weight")[:, 0, :]
             dwq = g(f"{p}.to_qk.mdl.3.sequential.1.conv.weight")[:, 0, :]
@@ -54,22 +68,22 @@ class PackedWeights:
             lw.os_gamma = dev(g(f"{p}.qk_offset_scale.gamma"))
             lw.os_beta = dev(g(f"{p}.qk_offset_scale.beta"))
             lw.rot_freqs = dev(g(f"{p}.rotary_pos_emb.freqs"))
-            lw.w_out = dev(g(f"{p}.to_out.mdl.1.weight") * g(f"{p}.to_out.mdl.0.g"))
+            lw.w_out = devw(g(f"{p}.to_out.mdl.1.weight") * g(f"{p}.to_out.mdl.0.g"))
             lw.b_out = dev(g(f"{p}.to_out.mdl.1.bias"))
             lw.dw_out = dev(g(f"{p}.to_out.mdl.3.sequential.1.conv.weight")[:, 0, :].t())
             q = f"{MDL}.fsmn.{i}"
-            lw.w_gg = dev(g(f"{q}.global_gate.0.weight"))
+            lw.w_gg = devw(g(f"{q}.global_gate.0.weight"))
             lw.b_gg = dev(g(f"{q}.global_gate.0.bias"))
             lw.w_in, lw.c1_in, lw.c2_in = fold_norm(g(f"{q}.proj_in.weight"), g(f"{q}.proj_in.bias"),
                                                     g(f"{q}.norm.weight"), g(f"{q}.norm.bias"))
-            lw.w_po = dev(g(f"{q}.proj_out.weight"))
+            lw.w_po = devw(g(f"{q}.proj_out.weight"))
             lw.b_po = dev(g(f"{q}.proj_out.bias"))
             for j in range(cfg.tcn_depth):
                 t = f"{q}.tcn.{j}"
                 tw = lw.tcn[j]
                 tw.dw_w = dev(g(f"{t}.net.0.weight")[:, 0, :].t())
                 tw.dw_b = dev(g(f"{t}.net.0.bias"))
-                tw.w_gate = dev(g(f"{t}.gate.0.weight")[:, :, 0])
+                tw.w_gate = devw(g(f"{t}.gate.0.weight")[:, :, 0])
                 tw.b_gate = dev(g(f"{t}.gate.0.bias"))
                 tw.w_pw, tw.c1, tw.c2 = fold_norm(g(f"{t}.net.3.weight")[:, :, 0], g(f"{t}.net.3.bias"),
                                                   g(f"{t}.net.2.weight"), g(f"{t}.net.2.bias"))
@@ -85,13 +99,13 @@ class PackedWeights:
         w.fin_ln_b = dev(g("mask_net.mdl.intra_mdl.norm.bias"))
         w.fin_gn_w = dev(g("mask_net.mdl.intra_norm.weight"))
         w.fin_gn_b = dev(g("mask_net.mdl.intra_norm.bias"))
-        w.w_co = dev(g("mask_net.conv1d_out.weight")[:, :, 0])
+        w.w_co = devw(g("mask_net.conv1d_out.weight")[:, :, 0])
         w.b_co = dev(g("mask_net.conv1d_out.bias"))
-        w.w_o = dev(g("mask_net.output.0.weight")[:, :, 0])
+        w.w_o = devw(g("mask_net.output.0.weight")[:, :, 0])
         w.b_o = dev(g("mask_net.output.0.bias"))
-        w.w_og = dev(g("mask_net.output_gate.0.weight")[:, :, 0])
+        w.w_og = devw(g("mask_net.output_gate.0.weight")[:, :, 0])
         w.b_og = dev(g("mask_net.output_gate.0.bias"))
-        w.w_cd = dev(g("mask_net.conv1_decoder.weight")[:, :, 0])
+        w.w_cd = devw(g("mask_net.conv1_decoder.weight")[:, :, 0])
         w.dec_w = dev(g("dec.weight")[:, 0, :])
         w.layers = C.cast(self.layers, C.POINTER(_lib.LayerWeights))
         self.struct = w

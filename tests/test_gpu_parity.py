@@ -231,6 +231,76 @@ def test_cpu_input_round_trip(models, golden_dir):
     assert np.abs(torch.stack(out, 0).numpy() - z["out"]).max() <= 1e-5
 
 
+# ------------------------------------------------------------ bf16 MFMA mode
+# bf16 operands (8 significant bits), fp32 accumulation: single contractions agree with
+# the fp64 oracle to ~1e-2 of the tensor's peak; the end-to-end gate is SI-SDR within
+# 0.05 dB of the fp32 reference output.
+BF = _lib.PREC_BF16
+
+
+def test_bf16_linear():
+    g = torch.Generator().manual_seed(13)
+    B, S, K, N = 2, 300, 512, 2176
+    x = torch.randn(B, S, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    xr = cpu_ref.scale_norm(cpu_ref.token_shift(x), torch.ones(1))
+    ref = torch.nn.functional.silu(xr.double() @ W.double().t() + b.double())
+    got = ops.linear(x.to(DEV), W.to(DEV), b.to(DEV), shift=True, scale_norm=True, act=1, precision=BF)
+    assert rel_err(got, ref) <= 1.5e-2
+    # exact on bf16-representable data: the only rounding left is fp32 accumulation
+    xq = x.to(torch.bfloat16).float()
+    Wq = W.to(torch.bfloat16).float()
+    got = ops.linear(xq.to(DEV), Wq.to(DEV), b.to(DEV), precision=BF)
+    assert rel_err(got, xq.double() @ Wq.double().t() + b.double()) <= 2e-6
+
+
+@pytest.mark.parametrize("B,S,E", [(2, 499, 128), (1, 700, 1024)])
+def test_bf16_flash_attention(B, S, E):
+    g = torch.Generator().manual_seed(14)
+    v = torch.randn(B, S, E, generator=g)
+    u = torch.randn(B, S, E, generator=g)
+    qk = torch.randn(B, S, 128, generator=g)
+    gam = 2.0 + 0.1 * torch.randn(4, 128, generator=g)
+    bet = 0.1 * torch.randn(4, 128, generator=g)
+    freqs = torch.from_numpy(make_state_dict(TINY)[f"{MDL}.layers.0.rotary_pos_emb.freqs"])
+    ref = cpu_ref.attention_core(v.double(), u.double(), qk.double(), gam.double(), bet.double(), freqs.double())
+    hu = torch.cat((v, u, qk), -1).contiguous()
+    got = ops.flash_attention(hu.to(DEV), gam.to(DEV), bet.to(DEV), freqs.to(DEV), precision=BF)
+    assert rel_err(got, ref) <= 3e-2
+
+
+def test_bf16_gated_tcn(small_w):
+    g = torch.Generator().manual_seed(15)
+    B, S, C = 2, 777, SMALL.dim
+    x = torch.randn(B, S, C, generator=g)
+    W64 = {k: v.double() for k, v in small_w.items()}
+    ref = cpu_ref.gated_tcn(x.double(), W64, f"{MDL}.fsmn.1")
+    pk = PackedWeights(small_w, SMALL, DEV, BF)
+    got = ops.gated_tcn(x.to(DEV).clone(), pk.layers[1], precision=BF)
+    assert rel_err(got, ref) <= 3e-2
+
+
+def test_bf16_full_model_si_sdr(golden_dir):
+    """bf16 MFMA mode against the fp32 reference output: SI-SDR of the separated
+    waveforms (against the synthetic sources) within 0.05 dB, and the waveforms
+    themselves close in the SI-SDR sense (estimate vs reference output > 30 dB)."""
+    from speech_separation_amd.synth import permute_si_sdr, si_sdr, synth_mixture
+    z = np.load(os.path.join(golden_dir, "fwd_full_B1_T32000.npz"))
+    m = MossFormerHIP(FULL_8K, compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(FULL_8K, 0).items()})
+    got = torch.stack(m(torch.from_numpy(z["input"]).to(DEV)), 0).cpu().numpy()
+    ref = z["out"]
+    mix, s1, s2 = synth_mixture(32000, 0)
+    assert np.array_equal(mix, z["input"][0])
+    d = permute_si_sdr(got[0, 0], got[1, 0], s1, s2) - permute_si_sdr(ref[0, 0], ref[1, 0], s1, s2)
+    fid = [si_sdr(got[s, 0], ref[s, 0]) for s in range(2)]
+    print(f"bf16 full model: SI-SDR delta {d:+.4f} dB; fidelity to fp32 reference {fid[0]:.1f} / {fid[1]:.1f} dB; "
+          f"max-abs {np.abs(got - ref).max():.3e} (peak {np.abs(ref).max():.3e})")
+    assert abs(d) <= 0.05
+    assert min(fid) >= 30.0
+
+
 # -------------------------------------------------- size-independent properties
 def test_full_size_batch_properties(models):
     """At the benchmark size (16 x 4 s, 24 layers): utterances in a batch are
