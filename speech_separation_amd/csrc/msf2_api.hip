@@ -37,7 +37,11 @@ template <int AMODE, int EPI>
 static void launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
-    launch_gemm<P>(c, grid, a);
+    // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16))
+        hipLaunchKernelGGL(gemm_kernel_bf16_dma<P>, grid, dim3(256), 0, c.st, a);
+    else
+        launch_gemm<P>(c, grid, a);
 }
 
 static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N, int S, float* out, int ldo) {
@@ -111,22 +115,70 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
 // ---- gated TCN block ----------------------------------------------------------
 struct TcnWs {
     float *rowstat, *g, *h0, *h1, *t, *part, *bstat;
+    unsigned short *h16a, *h16b, *t16;     // bf16 mode: operand images of h and t
     int nblk;
 };
-static TcnWs tcn_ws(Arena& ar, int B, int S, int C) {
-    TcnWs w;
+static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
+    TcnWs w = {};
     const long M = (long)B * S;
     w.nblk = cdiv(S, TCN_TS);
     w.rowstat = ar.take<float>(2 * M);
     w.g = ar.take<float>(M * C);
     w.h0 = ar.take<float>(M * C);
     w.h1 = ar.take<float>(M * C);
-    w.t = ar.take<float>(M * C);
+    if (prec == MSF2_PREC_BF16) {
+        w.h16a = ar.take<unsigned short>(M * C);
+        w.h16b = ar.take<unsigned short>(M * C);
+        w.t16 = ar.take<unsigned short>(M * C);
+    } else {
+        w.t = ar.take<float>(M * C);
+    }
     w.part = ar.take<float>(2L * B * w.nblk);
     w.bstat = ar.take<float>(2L * B);
     return w;
 }
+
+// bf16 mode: h lives twice, fp32 (residual chain, depthwise input) and bf16 (operand of the gate
+// projection); t and g*h are only ever contraction operands and live in bf16 alone.
+static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
+    {
+        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
+        a.bias = lw.b_gg; a.act = 2;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
+    {
+        ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, w.h0, C);
+        a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a;
+        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    }
+    float* h = w.h0;
+    float* hn = w.h1;
+    unsigned short* h16 = w.h16a;
+    unsigned short* hn16 = w.h16b;
+    for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
+        const msf2_tcn_weights& tw = lw.tcn[j];
+        const bool last = j == MSF2_TCN_DEPTH - 1;
+        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, (float*)nullptr,
+                           w.t16, w.part, c.S, C, 1 << j, TCN_TS);
+        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
+        ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, last ? nullptr : hn, C);
+        a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
+        a.bstat = w.bstat; a.res = h; a.ldr = C; a.out16 = hn16;
+        if (last) a.gmul = w.g;             // the last block hands g * h (bf16 only) to proj_out
+        launch_proj<A_PLAIN, EPI_TCN>(c, a);
+        float* tmp = h; h = hn; hn = tmp;
+        unsigned short* t16 = h16; h16 = hn16; hn16 = t16;
+    }
+    {
+        ProjArgs a = proj_args(nullptr, C, lw.w_po, C, C, c.S, x, C);
+        a.A16 = h16; a.bias = lw.b_po; a.res = x; a.ldr = C;
+        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
+    }
+}
+
 static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
+    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, lw, C); return; }
     // g = sigmoid(x Wgg^T + b)
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
@@ -144,7 +196,8 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_lay
     float* hn = w.h1;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part,
+        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, w.t,
+                           (unsigned short*)nullptr, w.part,
                            c.S, C, 1 << j, TCN_TS);
         launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
@@ -199,7 +252,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.fv = ar.take<float>(M * 16);
     w.zeros = ar.take<float>(64);
     w.at = attn_ws(ar, B, S, E);
-    w.tc = tcn_ws(ar, B, S, C);
+    w.tc = tcn_ws(ar, B, S, C, cfg.precision);
     return w;
 }
 
@@ -407,7 +460,7 @@ int msf2_flash_attention(const float* hu, int ldhu, const float* os_gamma, const
 
 size_t msf2_gated_tcn_ws_bytes(int B, int S, int C) {
     Arena ar(nullptr, 0);
-    tcn_ws(ar, B, S, C);
+    tcn_ws(ar, B, S, C, MSF2_PREC_BF16);   // the larger of the two layouts
     return ar.off;
 }
 
@@ -416,7 +469,7 @@ int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, 
     if (!x || !lw || !ws || B < 1 || S < 1 || !dim_ok(C)) return MSF2_ERR_ARG;
     if ((precision != MSF2_PREC_FP32 && precision != MSF2_PREC_BF16) || !fits32((long)B * S, C)) return MSF2_ERR_ARG;
     Arena ar(ws, ws_bytes);
-    TcnWs w = tcn_ws(ar, B, S, C);
+    TcnWs w = tcn_ws(ar, B, S, C, precision);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
     Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
     run_gated_tcn(c, w, x, *lw, C);

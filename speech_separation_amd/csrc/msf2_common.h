@@ -39,6 +39,14 @@ struct Arena {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// two floats -> packed bf16 pair (low half = a), round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pk_bf16_pair(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -46,6 +46,13 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
 __device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+// one float -> bf16 bits, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pk_bf16_1(float a) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {a, 0.f};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2)) & 0xffffu;
+}
 // uniform base + 32-bit byte offset: lowers to the saddr + voffset form of global_load / global_store
 __device__ __forceinline__ float ldg_off(const float* base, unsigned byte_off) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -280,6 +287,10 @@ struct ProjArgs {
     const float* gmul;      // EPI_TCN: optional elementwise gate multiplied onto the result, [B*S][ldo]
     const float* zeros;     // A_SHIFT: >= 128 bytes of zeros
     int act;
+    // bf16 mode: optional bf16 images of the A operands (same shape / pitch as A, A2) read by the
+    // DMA kernel, and an optional bf16 copy of the output written next to the fp32 one
+    const unsigned short* A16;  const unsigned short* A2_16;
+    unsigned short* out16;
 };
 
 template <int AMODE, int EPI>
@@ -323,6 +334,20 @@ struct ProjNT {
         if (NSEG == 2 && seg == 1) w = a.W2;
         n = min(n, a.N - 1);
         return w + (long)n * a.K + kt * BK + ko;
+    }
+    // bf16 image of the A operand (DMA kernel); same clamping and token shift as ptrA
+    __device__ const unsigned short* ptrA16(int seg, int kt, int r, int ko) const {
+        const int s = min(s0 + r, a.S - 1);
+        const int k = kt * BK + ko;
+        long row = (long)b * a.S + s;
+        const unsigned short* base = (NSEG == 2 && seg == 1) ? a.A2_16 : a.A16;
+        if (AMODE == A_SHIFT) {
+            const bool sh = k < (a.K >> 1);
+            row -= (sh && s > 0) ? 1 : 0;
+            const unsigned short* p = base + row * a.lda + k;
+            return (sh && s == 0) ? reinterpret_cast<const unsigned short*>(a.zeros) : p;
+        }
+        return base + row * a.lda + k;
     }
     // bf16 kernels: W / W2 point at bf16 weights [N][K]
     __device__ const unsigned short* ptrB16(int seg, int kt, int c, int ko) const {
@@ -419,8 +444,12 @@ struct ProjNT {
                         v = (rv[tn][reg] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1)) * gv[reg];
                     }
                     if (ok[reg] && nok) {
-                        stg_off(a.out, mrow[reg] * ldo4 + nc4, v);
+                        if (a.out) stg_off(a.out, mrow[reg] * ldo4 + nc4, v);
                         if (EPI == EPI_NORM && a.out2) stg_off(a.out2, mrow[reg] * ldo4 + nc4, v);
+                        if (a.out16) {
+                            const unsigned bits = pk_bf16_1(v);
+                            *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.out16) + ((mrow[reg] * ldo4 + nc4) >> 1)) = (unsigned short)bits;
+                        }
                     }
                 }
             }

@@ -171,4 +171,101 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Arg
     prob.template epilogue<TM, TN>(acc, wr, wc, lane);
 }
 
+// ---------------------------------------------------------------------------
+// bf16 x bf16 projections with BOTH operands already bf16 in HBM: tiles go
+// global -> LDS directly (global_load_lds_dwordx4) through a 4-stage ring, three
+// tiles in flight per workgroup (2 workgroups per CU, 96 KB outstanding per CU),
+// counted vmcnt + raw s_barrier so the prefetch stays in flight across barriers.
+// Both K segments of a two-accumulator problem run through one continuous ring.
+// One wave instruction moves 16 rows x 64 B; the swizzle is on the source address.
+// ---------------------------------------------------------------------------
+template <class P, bool IS_A>
+__device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, int kt, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int inst = wave * 2 + i;
+        const int row = inst * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ bf_swz(row);
+        const unsigned short* src;
+        if constexpr (IS_A) src = prob.ptrA16(seg, kt, row, chunk * 8);
+        else src = prob.ptrB16(seg, kt, row, chunk * 8);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + inst * 1024), 16, 0, 0);
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
+    constexpr int NST = 4;
+    __shared__ __attribute__((aligned(1024))) char sm[NST * 2 * BF_TILE];
+    P prob;
+    prob.init(args);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / P::WC, wc = wave % P::WC;
+    constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
+    f32x16 acc[P::NSEG][TM][TN];
+#pragma unroll
+    for (int s = 0; s < P::NSEG; ++s)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
+    const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG;
+    auto issue = [&](int t) {
+        const int seg = (P::NSEG == 2 && t >= nk0) ? 1 : 0;
+        const int kt = t - seg * nk0;
+        char* base = sm + (t & (NST - 1)) * 2 * BF_TILE;
+        bf_dma_tile<P, true>(prob, base, seg, kt, wave, lane);
+        bf_dma_tile<P, false>(prob, base + BF_TILE, seg, kt, wave, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nkt) issue(t);
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
+    auto step = [&](int t, f32x16 (&ac)[TM][TN]) {
+        // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
+        const int rem = nkt - 1 - t;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NST - 1 < nkt) issue(t + NST - 1);      // refills the slot every wave finished reading last step
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sa = sm + (t & (NST - 1)) * 2 * BF_TILE;
+        const char* sb = sa + BF_TILE;
+        bf16x8_t af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int q = 0; q < TM; ++q) af[st][q] = bf_frag(sa, rowA + q * 32, st, kh);
+#pragma unroll
+            for (int q = 0; q < TN; ++q) bf[st][q] = bf_frag(sb, rowB + q * 32, st, kh);
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    ac[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
+    };
+    for (int t = 0; t < nk0; ++t) step(t, acc[0]);
+    if constexpr (P::NSEG == 2)
+        for (int t = nk0; t < nkt; ++t) step(t, acc[1]);
+#ifdef MSF2_DIAG_NOEPI
+    {   // timing-only build: keep the accumulators alive with one conditional store
+        float sum = 0.f;
+        for (int s = 0; s < P::NSEG; ++s)
+            for (int tm = 0; tm < TM; ++tm)
+                for (int tn = 0; tn < TN; ++tn)
+                    for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
+        if (sum == 123.456f) sm[0] = (char)sum;
+    }
+#else
+    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+#endif
+}
+
 }  // namespace msf2

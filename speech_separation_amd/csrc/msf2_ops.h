@@ -229,9 +229,11 @@ __global__ void kv_finalize_kernel(const float* __restrict__ part, float* __rest
 }
 
 // ---- TCN stage A: t = silu(dwconv3_dilated(h) + bias), + partial sums --------
-// grid (ceil(S/TS), B), block 256.  w: [3][C]
+// t16 != nullptr: write t as bf16 there (the contraction that consumes it runs in bf16) instead of fp32 to t;
+// the statistics are always taken from the fp32 values.
 __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ t,
+                                                          unsigned short* __restrict__ t16,
                                                           float* __restrict__ part, int S, int C, int dil, int TS) {
     __shared__ float red[8];
     const QuadMap qm(C);
@@ -253,7 +255,14 @@ __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restric
         v.y = silu_f(w0.y * xm.y + w1.y * x0.y + w2.y * xp.y + bs.y);
         v.z = silu_f(w0.z * xm.z + w1.z * x0.z + w2.z * xp.z + bs.z);
         v.w = silu_f(w0.w * xm.w + w1.w * x0.w + w2.w * xp.w + bs.w);
-        *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+        if (t16) {
+            uint2 pk;
+            pk.x = pk_bf16_pair(v.x, v.y);
+            pk.y = pk_bf16_pair(v.z, v.w);
+            *reinterpret_cast<uint2*>(t16 + ((long)b * S + s) * C + c) = pk;
+        } else {
+            *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+        }
         sum += v.x + v.y + v.z + v.w;
         sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
