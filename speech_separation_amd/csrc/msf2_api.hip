@@ -124,8 +124,10 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     w.nblk = cdiv(S, TCN_TS);
     w.rowstat = ar.take<float>(2 * M);
     w.g = ar.take<float>(M * C);
-    w.h0 = ar.take<float>(M * C);
-    w.h1 = ar.take<float>(M * C);
+    if (prec != MSF2_PREC_BF16) {
+        w.h0 = ar.take<float>(M * C);
+        w.h1 = ar.take<float>(M * C);
+    }
     if (prec == MSF2_PREC_BF16) {
         w.h16a = ar.take<unsigned short>(M * C);
         w.h16b = ar.take<unsigned short>(M * C);
@@ -138,8 +140,8 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     return w;
 }
 
-// bf16 mode: h lives twice, fp32 (residual chain, depthwise input) and bf16 (operand of the gate
-// projection); t and g*h are only ever contraction operands and live in bf16 alone.
+// bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
+// and the 8-step residual chain of h); statistics, gates and the outer residual stream x stay fp32.
 static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
@@ -148,26 +150,22 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, const msf
     }
     launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
     {
-        ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, w.h0, C);
+        ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, nullptr, C);
         a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a;
         launch_proj<A_PLAIN, EPI_NORM>(c, a);
     }
-    float* h = w.h0;
-    float* hn = w.h1;
     unsigned short* h16 = w.h16a;
     unsigned short* hn16 = w.h16b;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        const bool last = j == MSF2_TCN_DEPTH - 1;
-        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, (float*)nullptr,
-                           w.t16, w.part, c.S, C, 1 << j, TCN_TS);
+        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, (const float*)nullptr, h16,
+                           tw.dw_w, tw.dw_b, (float*)nullptr, w.t16, w.part, c.S, C, 1 << j, TCN_TS);
         launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
-        ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, last ? nullptr : hn, C);
+        ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
-        a.bstat = w.bstat; a.res = h; a.ldr = C; a.out16 = hn16;
-        if (last) a.gmul = w.g;             // the last block hands g * h (bf16 only) to proj_out
+        a.bstat = w.bstat; a.res16 = h16; a.ldr = C; a.out16 = hn16;
+        if (j == MSF2_TCN_DEPTH - 1) a.gmul = w.g;   // the last block hands g * h to proj_out
         launch_proj<A_PLAIN, EPI_TCN>(c, a);
-        float* tmp = h; h = hn; hn = tmp;
         unsigned short* t16 = h16; h16 = hn16; hn16 = t16;
     }
     {
@@ -196,8 +194,8 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_lay
     float* hn = w.h1;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, tw.dw_w, tw.dw_b, w.t,
-                           (unsigned short*)nullptr, w.part,
+        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, (const unsigned short*)nullptr,
+                           tw.dw_w, tw.dw_b, w.t, (unsigned short*)nullptr, w.part,
                            c.S, C, 1 << j, TCN_TS);
         launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
@@ -459,9 +457,10 @@ int msf2_flash_attention(const float* hu, int ldhu, const float* os_gamma, const
 }
 
 size_t msf2_gated_tcn_ws_bytes(int B, int S, int C) {
-    Arena ar(nullptr, 0);
-    tcn_ws(ar, B, S, C, MSF2_PREC_BF16);   // the larger of the two layouts
-    return ar.off;
+    Arena a32(nullptr, 0), a16(nullptr, 0);
+    tcn_ws(a32, B, S, C, MSF2_PREC_FP32);
+    tcn_ws(a16, B, S, C, MSF2_PREC_BF16);
+    return a32.off > a16.off ? a32.off : a16.off;   // the larger of the two layouts
 }
 
 int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, int precision, void* ws, size_t ws_bytes,

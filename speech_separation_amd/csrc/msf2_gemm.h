@@ -291,6 +291,7 @@ struct ProjArgs {
     // DMA kernel, and an optional bf16 copy of the output written next to the fp32 one
     const unsigned short* A16;  const unsigned short* A2_16;
     unsigned short* out16;
+    const unsigned short* res16;   // residual read as bf16 instead of res (same pitch ldr)
 };
 
 template <int AMODE, int EPI>
@@ -396,7 +397,19 @@ struct ProjNT {
             for (int tn = 0; tn < TNE; ++tn) {
                 const unsigned nc4 = 4u * min(n0 + MSF2_ACC_COL(wc, TN, tn, lane), a.N - 1);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = RES ? ldg_off(a.res, mrow[reg] * ldr4 + nc4) : 0.f;
+                for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = 0.f;
+                if (RES && !a.res16) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = ldg_off(a.res, mrow[reg] * ldr4 + nc4);
+                }
+                if (RES && a.res16) {     // residual kept in bf16 (uniform branch)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const unsigned short h = *reinterpret_cast<const unsigned short*>(
+                            reinterpret_cast<const char*>(a.res16) + ((mrow[reg] * ldr4 + nc4) >> 1));
+                        rv[tn][reg] = __builtin_bit_cast(float, (unsigned)h << 16);
+                    }
+                }
                 if (EPI == EPI_NORM && a.pe) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = ldg_off(a.pe, (mrow[reg] - m_base) * (4u * a.N) + nc4);

@@ -231,7 +231,13 @@ __global__ void kv_finalize_kernel(const float* __restrict__ part, float* __rest
 // ---- TCN stage A: t = silu(dwconv3_dilated(h) + bias), + partial sums --------
 // t16 != nullptr: write t as bf16 there (the contraction that consumes it runs in bf16) instead of fp32 to t;
 // the statistics are always taken from the fp32 values.
-__global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const float* __restrict__ w,
+// h16 != nullptr: the input is read as bf16 from there instead of fp32 from h.
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 p) {
+    return make_float4(__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
+                       __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xffff0000u));
+}
+__global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const unsigned short* __restrict__ h16,
+                                                          const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ t,
                                                           unsigned short* __restrict__ t16,
                                                           float* __restrict__ part, int S, int C, int dil, int TS) {
@@ -243,13 +249,17 @@ __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restric
     const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
     const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
     const float4 bs = *reinterpret_cast<const float4*>(bias + c);
-    const float* hb = h + (long)b * S * C + c;
+    const long boff = (long)b * S * C + c;
     float sum = 0.f, sq = 0.f;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ldrow = [&](int s) -> float4 {
+        if (h16) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(h16 + boff + (long)s * C));
+        return *reinterpret_cast<const float4*>(h + boff + (long)s * C);
+    };
     for (int s = s0 + qm.fo; s < s1; s += qm.nf) {
-        const float4 xm = (s - dil >= 0) ? *reinterpret_cast<const float4*>(hb + (long)(s - dil) * C) : z;
-        const float4 x0 = *reinterpret_cast<const float4*>(hb + (long)s * C);
-        const float4 xp = (s + dil < S) ? *reinterpret_cast<const float4*>(hb + (long)(s + dil) * C) : z;
+        const float4 xm = (s - dil >= 0) ? ldrow(s - dil) : z;
+        const float4 x0 = ldrow(s);
+        const float4 xp = (s + dil < S) ? ldrow(s + dil) : z;
         float4 v;
         v.x = silu_f(w0.x * xm.x + w1.x * x0.x + w2.x * xp.x + bs.x);
         v.y = silu_f(w0.y * xm.y + w1.y * x0.y + w2.y * xp.y + bs.y);
