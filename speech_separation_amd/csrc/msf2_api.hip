@@ -38,9 +38,17 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
     // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
-    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16))
-        hipLaunchKernelGGL(gemm_kernel_bf16_dma<P>, grid, dim3(256), 0, c.st, a);
-    else
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16)) {
+        // one workgroup walks several column tiles of its row tile as long as that still
+        // leaves at least two full rounds of workgroups (512 resident at 2 per CU)
+        int loop = grid.x;
+        if (const char* e = getenv("MSF2_NCOL_LOOP")) loop = atoi(e) > 0 ? atoi(e) : 1;
+        while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
+        ProjArgs al = a;
+        al.ncol_loop = loop;
+        grid.x = cdiv(grid.x, loop);
+        hipLaunchKernelGGL(gemm_kernel_bf16_dma<P>, grid, dim3(256), 0, c.st, al);
+    } else
         launch_gemm<P>(c, grid, a);
 }
 

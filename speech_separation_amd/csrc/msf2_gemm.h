@@ -42,6 +42,20 @@ constexpr int RC_PITCH = BM + 4;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// One wave-level global -> LDS copy: lane l moves 16 bytes from its own source address to
+// lds_base + 16 * l (lds_base wave-uniform).  Written as inline assembly on purpose: when hipcc
+// sees the builtin form it treats every later ds_read as a possible reader of the copy and
+// places s_waitcnt vmcnt(0) in front of it, which serialises the prefetch with the MFMAs it is
+// meant to overlap.  Completion is tracked by hand instead (s_waitcnt vmcnt + barrier in the
+// callers); the "memory" clobber keeps the compiler's own LDS and global accesses in order.
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src), "s"(lds_base) : "memory", "m0");
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
 __device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
@@ -72,7 +86,7 @@ __device__ __forceinline__ void dma_tile(const P& prob, float* tile, int kt, int
         const float* src;
         if constexpr (IS_A) src = prob.ptrA(SEG, kt, row, chunk * 4);
         else src = prob.ptrB(SEG, kt, row, chunk * 4);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + inst * 256), 16, 0, 0);
+        dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile + inst * 256)));
     }
 }
 
@@ -292,6 +306,7 @@ struct ProjArgs {
     const unsigned short* A16;  const unsigned short* A2_16;
     unsigned short* out16;
     const unsigned short* res16;   // residual read as bf16 instead of res (same pitch ldr)
+    int ncol_loop;                 // DMA kernel: consecutive column tiles one workgroup walks (0 = 1); grid.x shrinks accordingly
 };
 
 template <int AMODE, int EPI>
@@ -310,7 +325,12 @@ struct ProjNT {
         const unsigned nt = t % gridDim.x, rest = t / gridDim.x;
         b = rest / gridDim.y;
         s0 = (rest % gridDim.y) * BM;
-        n0 = nt * (PAIRED ? BN / 2 : BN);
+        n0 = nt * (a.ncol_loop > 1 ? a.ncol_loop : 1) * NW;
+    }
+    static constexpr int NW = PAIRED ? BN / 2 : BN;     // output columns one tile covers
+    __device__ int col_tiles_here() const {            // tiles this workgroup walks (DMA kernel)
+        const int left = (a.N - n0 + NW - 1) / NW;
+        return min(a.ncol_loop > 1 ? a.ncol_loop : 1, left);
     }
     __device__ int nk(int) const { return a.K / BK; }
     // rows past the end of the utterance are clamped (their outputs are never stored)

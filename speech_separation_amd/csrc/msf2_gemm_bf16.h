@@ -189,7 +189,7 @@ __device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, 
         const unsigned short* src;
         if constexpr (IS_A) src = prob.ptrA16(seg, kt, row, chunk * 8);
         else src = prob.ptrB16(seg, kt, row, chunk * 8);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(tile + inst * 1024), 16, 0, 0);
+        dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile + inst * 1024)));
     }
 }
 
@@ -202,39 +202,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / P::WC, wc = wave % P::WC;
     constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
-    f32x16 acc[P::NSEG][TM][TN];
-#pragma unroll
-    for (int s = 0; s < P::NSEG; ++s)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
+    // A workgroup walks `nrep` consecutive column tiles of its row tile; the k tiles of all of
+    // them form one continuous stream through the ring, so the first tiles of the next column
+    // tile are already in flight while the epilogue of the current one runs, and the A rows are
+    // re-read out of L2 instead of four workgroups missing on them at the same moment.
     const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG;
-    auto issue = [&](int t) {
-        const int seg = (P::NSEG == 2 && t >= nk0) ? 1 : 0;
-        const int kt = t - seg * nk0;
-        char* base = sm + (t & (NST - 1)) * 2 * BF_TILE;
-        bf_dma_tile<P, true>(prob, base, seg, kt, wave, lane);
-        bf_dma_tile<P, false>(prob, base + BF_TILE, seg, kt, wave, lane);
+    const int nrep = prob.col_tiles_here();
+    const int total = nrep * nkt;
+    P pf = prob;                 // the prefetch position runs NST-1 tiles ahead of the consumer
+    int pf_t = 0, issued = 0;
+    auto issue = [&]() {
+        const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
+        const int kt = pf_t - seg * nk0;
+        char* base = sm + (issued & (NST - 1)) * 2 * BF_TILE;
+        bf_dma_tile<P, true>(pf, base, seg, kt, wave, lane);
+        bf_dma_tile<P, false>(pf, base + BF_TILE, seg, kt, wave, lane);
+        ++issued;
+        if (++pf_t == nkt) { pf_t = 0; pf.n0 += P::NW; }
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
-        if (t < nkt) issue(t);
+        if (issued < total) issue();
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
-    auto step = [&](int t, f32x16 (&ac)[TM][TN]) {
-        // tile t has landed once at most the DMA instructions of the tiles issued after it are outstanding
-        const int rem = nkt - 1 - t;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    int cons = 0;                // tiles consumed so far (all column tiles)
+    auto step = [&](bool fresh, f32x16 (&ac)[TM][TN]) {
+        // tile `cons` has landed once at most the DMA instructions of the tiles issued after it
+        // are outstanding; right after an epilogue its stores share the counter, so drain it all
+        // (the tiles waited for were issued before the epilogue started)
+        const int rem = total - 1 - cons;
+        if (fresh || rem == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + NST - 1 < nkt) issue(t + NST - 1);      // refills the slot every wave finished reading last step
+        if (issued < total) issue();                    // refills the slot every wave finished reading last step
         __builtin_amdgcn_sched_barrier(0);
-        const char* sa = sm + (t & (NST - 1)) * 2 * BF_TILE;
+        const char* sa = sm + (cons & (NST - 1)) * 2 * BF_TILE;
         const char* sb = sa + BF_TILE;
+        ++cons;
         bf16x8_t af[2][TM], bf[2][TN];
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
@@ -251,21 +256,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
                 for (int tn = 0; tn < TN; ++tn)
                     ac[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
     };
-    for (int t = 0; t < nk0; ++t) step(t, acc[0]);
-    if constexpr (P::NSEG == 2)
-        for (int t = nk0; t < nkt; ++t) step(t, acc[1]);
-#ifdef MSF2_DIAG_NOEPI
-    {   // timing-only build: keep the accumulators alive with one conditional store
-        float sum = 0.f;
+    for (int rep = 0; rep < nrep; ++rep) {
+        f32x16 acc[P::NSEG][TM][TN];
+#pragma unroll
         for (int s = 0; s < P::NSEG; ++s)
+#pragma unroll
             for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
-        if (sum == 123.456f) sm[0] = (char)sum;
-    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
+        for (int t = 0; t < nk0; ++t) step(rep > 0 && t == 0, acc[0]);
+        if constexpr (P::NSEG == 2)
+            for (int t = nk0; t < nkt; ++t) step(false, acc[1]);
+#ifdef MSF2_DIAG_NOEPI
+        {   // timing-only build: keep the accumulators alive with one conditional store
+            float sum = 0.f;
+            for (int s = 0; s < P::NSEG; ++s)
+                for (int tm = 0; tm < TM; ++tm)
+                    for (int tn = 0; tn < TN; ++tn)
+                        for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
+            if (sum == 123.456f) sm[0] = (char)sum;
+        }
 #else
-    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+        prob.template epilogue<TM, TN>(acc, wr, wc, lane);
 #endif
+        prob.n0 += P::NW;
+    }
 }
 
 }  // namespace msf2
