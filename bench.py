@@ -25,40 +25,38 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def dominant_kernel_probe(model, B, T, reps=20):
-    """Average launch duration of the dominant kernel -- the fused pointwise
-    half of a TCN block, gemm_kernel<ProjNT<0,5>>: [B*S, 512] x two 512x512
-    weights with the gate / GroupNorm / residual epilogue; 8 launches per layer
-    x 24 layers = 53 % of the forward's FLOPs -- timed live with HIP events on
-    the stream it is launched on, through the C ABI, at the benchmark shape."""
+def dominant_kernel_probe(model, step, B, T):
+    """Average launch duration of the dominant kernel -- the fused pointwise half of a TCN
+    block (gemm_kernel<ProjNT<0,5>> in fp32, gemm_kernel_bf16_dma<ProjNT<0,5>> in bf16):
+    [B*S, 512] x two 512x512 weights with the gate / GroupNorm / residual epilogue, 8 launches
+    per layer x 24 layers = 53 % of the forward's FLOPs.  Measured in place: one more step of
+    the benchmark workload runs with the library's kernel timer on, which brackets each of its
+    192 launches with HIP events on the stream they are launched on."""
+    import ctypes
     from speech_separation_amd import _lib
     lib = _lib.load()
-    pk = model.packed()
-    dev = pk.device
     S = lib.msf2_num_frames(T)
     C = model.cfg.dim
-    h = torch.randn(B, S, C, device=dev)
-    t = torch.randn(B, S, C, device=dev)
-    ho = torch.empty_like(h)
-    bstat = torch.tensor([[0.1, 1.3]] * B, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    tw = pk.layers[0].tcn[0]
-
-    def run():
-        _lib.check(lib.msf2_tcn_pointwise(h.data_ptr(), t.data_ptr(), bstat.data_ptr(), tw, ho.data_ptr(),
-                                          B, S, C, pk.c_cfg.precision, stream.cuda_stream))
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(reps):
-        run()
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / reps
+    _lib.check(lib.msf2_timing_begin())
+    step()
+    total, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    _lib.check(lib.msf2_timing_end(ctypes.byref(total), ctypes.byref(n)))
+    if n.value == 0:
+        raise SystemExit("kernel timer saw no launch of the TCN pointwise kernel")
     flops = 2.0 * B * S * 2 * C * C          # two [M,C]x[C,C] products per launch
-    return ms, flops
+    return total.value / n.value, flops, n.value
+
+
+def measured_traffic(precision, B, T):
+    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/
+    (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs, FETCH_SIZE doubled as gfx950
+    requires); None when no measurement exists for this precision and shape."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_tcn_pointwise_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[f"{precision}_b{B}_t{T}"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -148,20 +146,22 @@ def main():
     }
 
     if rank == 0:
-        ms, flops = dominant_kernel_probe(model, B, T)
+        ms, flops, nl = dominant_kernel_probe(model, step, B, T)
+        traffic = measured_traffic(a.precision, B, T)
         if prec == _lib.PREC_FP32:
             peak = 157.3
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
                                "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                               "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
-                               "launch_ms": ms}
+                               "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": traffic,
+                               "launch_ms": ms, "launches_timed": nl}
         else:
-            # at bf16 MFMA rates the same kernel is bandwidth bound: it must read h and t and write h' once
+            # at bf16 MFMA rates the same kernel is bandwidth bound: it must read the bf16 images of h and t
+            # and write the bf16 image of h' once (2 bytes per element each)
             S_ = model.cfg.frames(T)
-            gbytes = 3.0 * B * S_ * cfg.dim * 4 / 1e9
-            res["roofline"] = {"bound": "hbm", "kernel": "gemm_kernel_bf16<ProjNT<0,5>> (TCN pointwise, bf16 MFMA 32x32x16)",
+            gbytes = 3.0 * B * S_ * cfg.dim * 2 / 1e9
+            res["roofline"] = {"bound": "hbm", "kernel": "gemm_kernel_bf16_dma<ProjNT<0,5>> (TCN pointwise, bf16 MFMA 32x32x16)",
                                "achieved": gbytes / (ms * 1e-3), "peak": 8000.0, "unit": "GB/s",
-                               "frac": gbytes / (ms * 1e-3) / 8000.0, "traffic": None, "launch_ms": ms,
+                               "frac": gbytes / (ms * 1e-3) / 8000.0, "traffic": traffic, "launch_ms": ms, "launches_timed": nl,
                                "tflops": flops / (ms * 1e-3) / 1e12}
         if not a.no_cpu_baseline and world == 1:
             from oracle import cpu_ref           # the CPU port that is timed, never the product path
@@ -173,7 +173,7 @@ def main():
                 c0 = time.perf_counter()
                 ref = cpu_ref.forward(W, xs, cfg)
                 cdt = time.perf_counter() - c0
-            got = torch.stack(model(xs.to(dev)), 0).cpu().numpy()
+            got = out[:, :1].cpu().numpy()       # utterance 0 of the last timed step (same seed as the CPU sample)
             refn = torch.stack(ref, 0).numpy()
             mix, s1, s2 = synth_mixture(T, 0)
             sdr_cpu = permute_si_sdr(refn[0, 0], refn[1, 0], s1, s2)

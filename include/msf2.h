@@ -137,6 +137,15 @@ int msf2_version(void);
  * 3 msf2_weights, 4 msf2_taps; -1 for any other index. */
 int msf2_sizeof(int which);
 
+/* Measurement aid with no counterpart in the reference (the reference times whole
+ * utterances only, utils/decode.py callers in inference.py:80-95).  Between
+ * msf2_timing_begin and msf2_timing_end every launch of the dominant kernel -- the
+ * pointwise contraction of a TCN block -- is bracketed by HIP events on the stream it
+ * is launched on; msf2_timing_end waits for them and returns their summed duration
+ * and count.  One thread at a time; keep it off inside a timed region. */
+int msf2_timing_begin(void);
+int msf2_timing_end(double* total_ms, int* launches);
+
 /* Frames produced by the encoder for T samples: (T - 16) / 8 + 1. */
 int msf2_num_frames(int T);
 

@@ -1,6 +1,8 @@
 // libmsf2: C-ABI entry points and the host-side launch sequence of the
 // MossFormer2_SS forward pass.  All work is enqueued on the caller's stream;
-// nothing here allocates, synchronises or keeps mutable global state.
+// nothing here allocates, synchronises or keeps mutable global state -- except the
+// opt-in kernel timer below (off by default, a measurement aid for one thread).
+#include <vector>
 #include "msf2_common.h"
 #include "msf2_gemm.h"
 #include "msf2_gemm_bf16.h"
@@ -9,6 +11,29 @@
 namespace msf2 {
 
 thread_local int g_last_hip_error = 0;
+
+// Between msf2_timing_begin() and msf2_timing_end() every launch of the TCN pointwise
+// contraction (the kernel that dominates the forward pass) is bracketed by a pair of HIP events
+// recorded on the stream it is launched on, so its duration is measured where it runs, on the
+// data it runs on.  Events cost a few microseconds each: never leave it on in a timed region.
+struct KernelTimer {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+};
+static KernelTimer g_timer;
+struct TimedLaunch {
+    hipStream_t st;
+    bool on;
+    TimedLaunch(hipStream_t s, bool wanted) : st(s), on(wanted && g_timer.on && g_timer.ev.size() < 8192) { mark(); }
+    ~TimedLaunch() { mark(); }
+    void mark() {
+        if (!on) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        hipEventRecord(e, st);
+        g_timer.ev.push_back(e);
+    }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool dim_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
@@ -38,6 +63,7 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
     // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
+    const TimedLaunch timed_(EPI == EPI_TCN ? c.st : nullptr, EPI == EPI_TCN);
     if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16)) {
         // one workgroup walks several column tiles of its row tile as long as that still
         // leaves at least two full rounds of workgroups (512 resident at 2 per CU)
@@ -299,6 +325,29 @@ int msf2_sizeof(int which) {
         case 4: return (int)sizeof(msf2_taps);
         default: return -1;
     }
+}
+int msf2_timing_begin(void) {
+    for (hipEvent_t e : g_timer.ev) hipEventDestroy(e);
+    g_timer.ev.clear();
+    g_timer.on = true;
+    return MSF2_OK;
+}
+int msf2_timing_end(double* total_ms, int* launches) {
+    g_timer.on = false;
+    double sum = 0.0;
+    int n = 0, rc = MSF2_OK;
+    for (size_t i = 0; i + 1 < g_timer.ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_timer.ev[i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]) != hipSuccess) { rc = MSF2_ERR_LAUNCH; break; }
+        sum += ms;
+        ++n;
+    }
+    for (hipEvent_t e : g_timer.ev) hipEventDestroy(e);
+    g_timer.ev.clear();
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = n;
+    return rc;
 }
 int msf2_num_frames(int T) { return T < 16 ? 0 : (T - 16) / 8 + 1; }
 

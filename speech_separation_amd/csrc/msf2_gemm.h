@@ -361,6 +361,9 @@ struct ProjNT {
         const int s = min(s0 + r, a.S - 1);
         const int k = kt * BK + ko;
         long row = (long)b * a.S + s;
+#ifdef MSF2_DIAG_SAMEROW
+        row = r;      // timing-only build: every workgroup reads the same (cache-resident) rows
+#endif
         const unsigned short* base = (NSEG == 2 && seg == 1) ? a.A2_16 : a.A16;
         if (AMODE == A_SHIFT) {
             const bool sh = k < (a.K >> 1);
