@@ -11,6 +11,7 @@
 namespace msf2 {
 
 thread_local int g_last_hip_error = 0;
+thread_local bool g_bad_operand = false;
 
 // Between msf2_timing_begin() and msf2_timing_end() every launch of the TCN pointwise
 // contraction (the kernel that dominates the forward pass) is bracketed by a pair of HIP events
@@ -63,6 +64,14 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
     // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
+    // the epilogue moves 4 consecutive columns per lane as one vector
+    auto al = [](const void* p, unsigned mask) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; };
+    if ((a.N & 3) || (a.ldo & 3) || (a.ldr & 3) || !al(a.out, 15) || !al(a.out2, 15) || !al(a.res, 15) || !al(a.pe, 15) ||
+        !al(a.gmul, 15) || !al(a.bias, 15) || !al(a.bias2, 15) || !al(a.c1, 15) || !al(a.c2, 15) || !al(a.out16, 7) ||
+        !al(a.res16, 7)) {
+        g_bad_operand = true;
+        return;
+    }
     const TimedLaunch timed_(EPI == EPI_TCN ? c.st : nullptr, EPI == EPI_TCN);
     if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16)) {
         // one workgroup walks several column tiles of its row tile as long as that still

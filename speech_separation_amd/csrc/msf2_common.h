@@ -10,8 +10,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace msf2 {
 
 extern thread_local int g_last_hip_error;
+extern thread_local bool g_bad_operand;     // a launcher refused an operand (alignment / pitch) and skipped its launch
 
 inline int check_launch() {
+    if (g_bad_operand) {
+        g_bad_operand = false;
+        (void)hipGetLastError();
+        return MSF2_ERR_ARG;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

@@ -74,6 +74,30 @@ __device__ __forceinline__ float ldg_off(const float* base, unsigned byte_off) {
 __device__ __forceinline__ void stg_off(float* base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+__device__ __forceinline__ float4 ldg4_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void stg4_off(float* base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+// 4 consecutive bf16 <-> float4 (8-byte accesses)
+__device__ __forceinline__ float4 ldg4_bf16_off(const unsigned short* base, unsigned byte_off) {
+    const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + byte_off);
+    return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                       __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned pk_bf16_2(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+__device__ __forceinline__ void stg4_bf16_off(unsigned short* base, unsigned byte_off, float4 v) {
+    uint2 h;
+    h.x = pk_bf16_2(v.x, v.y);
+    h.y = pk_bf16_2(v.z, v.w);
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + byte_off) = h;
+}
 
 // ---- k-contiguous operand: 16 KiB tile = 16 wave-level DMA instructions, 4 per wave
 template <class P, int SEG, bool IS_A>
@@ -171,8 +195,9 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(af[c & 1][tm], j), f4get(bf[c & 1][tn], j),
-                                                                           acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = P::ACC_T
+                            ? __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(bf[c & 1][tn], j), f4get(af[c & 1][tm], j), acc[tm][tn], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(af[c & 1][tm], j), f4get(bf[c & 1][tn], j), acc[tm][tn], 0, 0, 0);
         }
     };
     // steady state is branch-free (a conditional around the staging makes hipcc merge
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
 #ifdef MSF2_DIAG_STAMP
     MSF2_STAMP(tk1)
 #endif
-    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+    prob.template epilogue<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);   // main loop ended with a barrier: LDS is free
 #ifdef MSF2_DIAG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MSF2_STAMP(tk2)
@@ -317,6 +342,7 @@ struct ProjNT {
     static constexpr int NSEG = (EPI == EPI_TCN) ? 2 : 1;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
     static constexpr bool B_BF16 = true;    // bf16 kernels read W as bf16
+    static constexpr bool ACC_T = true;     // accumulators transposed: MFMA(weight fragment, activation fragment)
     Args a;
     int b, s0, n0;
     __device__ void init(const Args& args) {
@@ -382,12 +408,22 @@ struct ProjNT {
         n = min(n, a.N - 1);
         return reinterpret_cast<const unsigned short*>(w) + (long)n * a.K + kt * BK + ko;
     }
-    // All loads of the epilogue are issued up front from clamped addresses (no branch
-    // between them), so the tile pays one memory round trip; only stores are predicated.
-    // Addresses are uniform base + 32-bit byte offset (the host rejects shapes whose
-    // buffers exceed 4 GiB), which keeps the address arithmetic out of 64-bit VGPR pairs.
+    // Accumulators are held TRANSPOSED (ACC_T: the kernels issue the MFMA with the weight fragment
+    // as its first operand): in a 32x32 tile lane l owns token row (l & 31) and, per group
+    // g = 0..3, the 4 CONSECUTIVE output columns 8 g + 4 (l >> 5) + 0..3 (register 4 g + e).
+    // Each tile is finished in two phases.  Phase 1, in that layout: everything that needs only the
+    // accumulators, per-row statistics and per-column vectors (float4 loads shared by a half wave);
+    // the result goes to a wave-private 4 KiB LDS tile as one 16-byte write per lane and group
+    // (16-byte chunk c of row r stored at chunk c ^ (r & 7): conflict-free both ways).  Phase 2,
+    // row-major: lane l takes rows 8 i + (l >> 3), i = 0..3, columns 4 (l & 7) + 0..3, so residual,
+    // gate, positional and output accesses are 16-byte (fp32) / 8-byte (bf16) vectors and one wave
+    // instruction covers 8 rows x 128 contiguous bytes.  All global loads of a tile are issued up
+    // front from clamped addresses; only stores are predicated.  Addresses are uniform base + 32-bit
+    // byte offset (the host rejects buffers beyond 4 GiB and pointers that are not 16-byte aligned;
+    // N is a multiple of 4).  LDS accesses of one wave execute in program order, so the two phases
+    // need no barrier, only the compiler fence.
     template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane) const {
+    __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage) const {
         float mean_b = 0.f, rstd_b = 1.f;
         if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
         constexpr int TNE = PAIRED ? TN / 2 : TN;
@@ -396,98 +432,106 @@ struct ProjNT {
         const bool has_rs = a.rowstat != nullptr;
         const bool has_g = (EPI == EPI_TCN) && a.gmul != nullptr;
         const unsigned ldr4 = 4u * a.ldr, ldo4 = 4u * a.ldo, m_base = (unsigned)b * a.S;
+        const int kh = lane >> 5, ar = lane & 31;      // accumulator layout
+        const int rr = lane >> 3, rc = lane & 7;       // row-major layout
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            unsigned mrow[16];
-            bool ok[16];
-            float r0[16], r1[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int s = s0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
-                ok[reg] = s < a.S;
-                mrow[reg] = m_base + min(s, a.S - 1);
-                r0[reg] = 1.f; r1[reg] = 0.f;
-            }
+            const int srow = s0 + wr * (TM * 32) + tm * 32;
+            float r0 = 1.f, r1 = 0.f;
             if (ROWSTAT && has_rs) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if (EPI == EPI_RS_BIAS_ACT) r0[reg] = ldg_off(a.rowstat, mrow[reg] * 4u);
-                    else { r1[reg] = ldg_off(a.rowstat, mrow[reg] * 8u); r0[reg] = ldg_off(a.rowstat, mrow[reg] * 8u + 4u); }
-                }
+                const unsigned ma = m_base + min(srow + ar, a.S - 1);
+                if (EPI == EPI_RS_BIAS_ACT) r0 = ldg_off(a.rowstat, ma * 4u);
+                else { r1 = ldg_off(a.rowstat, ma * 8u); r0 = ldg_off(a.rowstat, ma * 8u + 4u); }
             }
-            float rv[TNE][16];
+            const float mu = (EPI == EPI_NORM && has_rs) ? r1 : mean_b, rs = (EPI == EPI_NORM && has_rs) ? r0 : rstd_b;
+            unsigned mrow[4];
+            bool ok[4];
 #pragma unroll
-            for (int tn = 0; tn < TNE; ++tn) {
-                const unsigned nc4 = 4u * min(n0 + MSF2_ACC_COL(wc, TN, tn, lane), a.N - 1);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = 0.f;
-                if (RES && !a.res16) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = ldg_off(a.res, mrow[reg] * ldr4 + nc4);
-                }
-                if (RES && a.res16) {     // residual kept in bf16 (uniform branch)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const unsigned short h = *reinterpret_cast<const unsigned short*>(
-                            reinterpret_cast<const char*>(a.res16) + ((mrow[reg] * ldr4 + nc4) >> 1));
-                        rv[tn][reg] = __builtin_bit_cast(float, (unsigned)h << 16);
-                    }
-                }
-                if (EPI == EPI_NORM && a.pe) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) rv[tn][reg] = ldg_off(a.pe, (mrow[reg] - m_base) * (4u * a.N) + nc4);
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int s = srow + 8 * i + rr;
+                ok[i] = s < a.S;
+                mrow[i] = m_base + min(s, a.S - 1);
             }
 #pragma unroll
             for (int tn = 0; tn < TNE; ++tn) {
-                const int n = n0 + MSF2_ACC_COL(wc, TN, tn, lane);
+                const int ncol = n0 + wc * (TN * 32) + tn * 32;
+                const int n = ncol + 4 * rc;
                 const bool nok = n < a.N;
-                const int nc = min(n, a.N - 1);
-                const unsigned nc4 = 4u * nc;
-                const float bias = a.bias ? a.bias[nc] : 0.f;
-                const float bias2 = (EPI == EPI_TANH_SIG) ? a.bias2[nc] : 0.f;
-                const float c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c1[nc] : 0.f;
-                const float c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? a.c2[nc] : 0.f;
-                float gv[16];
+                const unsigned nc4 = 4u * min(n, a.N - 4);
+                float4 rv[4], gv[4];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) gv[reg] = 1.f;
-                if (has_g) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) gv[reg] = ldg_off(a.gmul, mrow[reg] * ldo4 + nc4);
+                for (int i = 0; i < 4; ++i) {
+                    rv[i] = zero4;
+                    gv[i] = one4;
+                    if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
+                    if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                    if (EPI == EPI_NORM && a.pe) rv[i] = ldg4_off(a.pe, (mrow[i] - m_base) * (4u * a.N) + nc4);
+                    if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
                 }
+                // phase 1
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float x = acc[0][tm][tn][reg];
-                    float v;
-                    if constexpr (EPI == EPI_RS_BIAS_ACT) {
-                        v = r0[reg] * x + bias;
-                        if (a.act == 1) v = silu_f(v);
-                        else if (a.act == 2) v = sigmoid_f(v);
-                    } else if constexpr (EPI == EPI_NORM) {
-                        const float mu = has_rs ? r1[reg] : mean_b, rs = has_rs ? r0[reg] : rstd_b;
-                        v = rs * (x - mu * c2) + c1 + rv[tn][reg];
-                    } else if constexpr (EPI == EPI_BIAS_RES) {
-                        v = rv[tn][reg] + x + bias;
-                    } else if constexpr (EPI == EPI_RELU_MUL) {
-                        v = fmaxf(x, 0.f);
-                        if (a.out2 && ok[reg] && nok) stg_off(a.out2, mrow[reg] * ldo4 + nc4, v);
-                        v *= rv[tn][reg];
-                    } else if constexpr (EPI == EPI_TANH_SIG) {
-                        const float y = acc[0][tm][tn + TN / 2][reg];
-                        v = tanhf(x + bias) * sigmoid_f(y + bias2);
-                    } else {  // EPI_TCN
-                        const float y = acc[NSEG - 1][tm][tn][reg];
-                        v = (rv[tn][reg] + sigmoid_f(x + bias) * (rstd_b * (y - mean_b * c2) + c1)) * gv[reg];
-                    }
-                    if (ok[reg] && nok) {
-                        if (a.out) stg_off(a.out, mrow[reg] * ldo4 + nc4, v);
-                        if (EPI == EPI_NORM && a.out2) stg_off(a.out2, mrow[reg] * ldo4 + nc4, v);
-                        if (a.out16) {
-                            const unsigned bits = pk_bf16_1(v);
-                            *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.out16) + ((mrow[reg] * ldo4 + nc4) >> 1)) = (unsigned short)bits;
+                for (int g = 0; g < 4; ++g) {
+                    const int nc = min(ncol + 8 * g + 4 * kh, a.N - 4);
+                    const float4 bias = a.bias ? ld4(a.bias + nc) : zero4;
+                    const float4 bias2 = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
+                    const float4 c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c1 + nc) : zero4;
+                    const float4 c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c2 + nc) : zero4;
+                    float p[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int reg = 4 * g + e;
+                        const float x = acc[0][tm][tn][reg];
+                        const float be = f4get(bias, e);
+                        if constexpr (EPI == EPI_RS_BIAS_ACT) {
+                            p[e] = r0 * x + be;
+                            if (a.act == 1) p[e] = silu_f(p[e]);
+                            else if (a.act == 2) p[e] = sigmoid_f(p[e]);
+                        } else if constexpr (EPI == EPI_NORM) {
+                            p[e] = rs * (x - mu * f4get(c2, e)) + f4get(c1, e);
+                        } else if constexpr (EPI == EPI_BIAS_RES) {
+                            p[e] = x + be;
+                        } else if constexpr (EPI == EPI_RELU_MUL) {
+                            p[e] = fmaxf(x, 0.f);
+                        } else if constexpr (EPI == EPI_TANH_SIG) {
+                            const float y = acc[0][tm][tn + TN / 2][reg];
+                            p[e] = tanhf(x + be) * sigmoid_f(y + f4get(bias2, e));
+                        } else {  // EPI_TCN
+                            const float y = acc[NSEG - 1][tm][tn][reg];
+                            p[e] = sigmoid_f(x + be) * (rstd_b * (y - mean_b * f4get(c2, e)) + f4get(c1, e));
                         }
                     }
+                    *reinterpret_cast<float4*>(stage + (ar * 8 + ((2 * g + kh) ^ (ar & 7))) * 4) = make_float4(p[0], p[1], p[2], p[3]);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // phase 2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + rr;
+                    const float4 p4 = *reinterpret_cast<const float4*>(stage + (row * 8 + (rc ^ (row & 7))) * 4);
+                    float4 v;
+                    if constexpr (EPI == EPI_RS_BIAS_ACT || EPI == EPI_TANH_SIG) {
+                        v = p4;
+                    } else if constexpr (EPI == EPI_NORM || EPI == EPI_BIAS_RES) {
+                        v = make_float4(p4.x + rv[i].x, p4.y + rv[i].y, p4.z + rv[i].z, p4.w + rv[i].w);
+                    } else if constexpr (EPI == EPI_RELU_MUL) {
+                        v = make_float4(p4.x * rv[i].x, p4.y * rv[i].y, p4.z * rv[i].z, p4.w * rv[i].w);
+                    } else {  // EPI_TCN
+                        v = make_float4((rv[i].x + p4.x) * gv[i].x, (rv[i].y + p4.y) * gv[i].y,
+                                        (rv[i].z + p4.z) * gv[i].z, (rv[i].w + p4.w) * gv[i].w);
+                    }
+                    if (ok[i] && nok) {
+                        const unsigned off = mrow[i] * ldo4 + nc4;
+                        if (a.out) stg4_off(a.out, off, v);
+                        if (EPI == EPI_NORM && a.out2) stg4_off(a.out2, off, v);
+                        if (EPI == EPI_RELU_MUL && a.out2) stg4_off(a.out2, off, p4);
+                        if (a.out16) stg4_bf16_off(a.out16, off >> 1, v);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);   // one tile at a time: accumulator reads are not hoisted across tiles
             }
         }
     }
@@ -509,6 +553,7 @@ struct AttnSim {
     typedef SimArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
     static constexpr bool B_BF16 = false;
+    static constexpr bool ACC_T = false;
     Args a;
     int b, g, m0, n0;
     __device__ void init(const Args& args) {
@@ -524,7 +569,7 @@ struct AttnSim {
     __device__ const float* ptrA(int, int kt, int r, int ko) const { return row(a.q, m0 + r, kt * BK + ko); }
     __device__ const float* ptrB(int, int kt, int c, int ko) const { return row(a.k, n0 + c, kt * BK + ko); }
     template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
+    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
         float* P = a.P + (long)blockIdx.z * MSF2_GROUP * MSF2_GROUP;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -556,6 +601,7 @@ struct LinKV {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
     static constexpr bool B_BF16 = false;
+    static constexpr bool ACC_T = false;
     Args a;
     int b, k0, k1, n0;
     __device__ void init(const Args& args) {
@@ -577,7 +623,7 @@ struct LinKV {
         return mul4(ld4(a.hu + ((long)b * a.S + min(s, k1 - 1)) * a.ldhu + n0 + c), m);
     }
     template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
+    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
         float* out = a.part + ((long)b * gridDim.y + blockIdx.y) * MSF2_QK_DIM * a.N;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -611,6 +657,7 @@ struct AttnOut {
     typedef AttnOutArgs Args;
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
     static constexpr bool B_BF16 = false;
+    static constexpr bool ACC_T = false;
     static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
     int z, b, g, m0, j0;
@@ -639,7 +686,7 @@ struct AttnOut {
         return mul4(ld4(kt < KT_QUAD ? pq : pl), m);
     }
     template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane) const {
+    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
         const unsigned ldh4 = 4u * a.ldhu, e4 = 4u * a.E;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {

@@ -131,7 +131,8 @@ __device__ __forceinline__ void run_segment_bf16(const P& prob, char* smA, char*
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = P::ACC_T ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st][tn], af[st][tm], acc[tm][tn], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], acc[tm][tn], 0, 0, 0);
     };
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int cur = kt & 1;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Arg
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
     run_segment_bf16<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wr, wc);
     if constexpr (P::NSEG == 2) run_segment_bf16<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wr, wc);
-    prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+    prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(smA) + (tid >> 6) * 1024);
 }
 
 // ---------------------------------------------------------------------------
@@ -199,7 +200,7 @@ __device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, 
 template <class P>
 __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
     constexpr int NST = 4;
-    __shared__ __attribute__((aligned(1024))) char sm[NST * 2 * BF_TILE];
+    __shared__ __attribute__((aligned(1024))) char sm[NST * 2 * BF_TILE + 4 * 4096];   // ring + one 4 KiB epilogue tile per wave
     P prob;
     prob.init(args);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    ac[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
+                    ac[tm][tn] = P::ACC_T ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st][tn], af[st][tm], ac[tm][tn], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
     };
     for (int rep = 0; rep < nrep; ++rep) {
         f32x16 acc[P::NSEG][TM][TN];
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
             if (sum == 123.456f) sm[0] = (char)sum;
         }
 #else
-        prob.template epilogue<TM, TN>(acc, wr, wc, lane);
+        prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(sm + NST * 2 * BF_TILE) + wave * 1024);
 #endif
         prob.n0 += P::NW;
     }
