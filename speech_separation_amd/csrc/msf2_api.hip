@@ -102,9 +102,10 @@ static void launch_rowstat(const Ctx& c, const float* x, int ldx, float* out, in
     hipLaunchKernelGGL(rowstat_kernel<MODE>, dim3(cdiv(c.M, 4)), dim3(256), 0, c.st, x, ldx, out, c.M, c.S, C, shift, eps);
 }
 
-static void launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate) {
+static void launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate,
+                            unsigned short* y16 = nullptr) {
     dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
-    hipLaunchKernelGGL(dwconv17_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate);
+    hipLaunchKernelGGL(dwconv17_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16);
 }
 
 // ---- FLASH attention core ---------------------------------------------------
@@ -132,7 +133,7 @@ static AttnWs attn_ws(Arena& ar, int B, int S, int E) {
     return w;
 }
 static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ldhu, const float* gamma,
-                          const float* beta, const float* freqs, float* o, int E) {
+                          const float* beta, const float* freqs, float* o, int E, unsigned short* o16 = nullptr) {
     const long M = c.M;
     hipLaunchKernelGGL(qk_prep_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, hu + 2 * E, ldhu, gamma, beta, freqs, w.q4, M, c.S);
     const float* quad_q = w.q4;
@@ -150,7 +151,7 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
         launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
     }
     {
-        AttnOutArgs a = {w.P, lin_q, hu, ldhu, w.kv, o, c.S, w.G, E};
+        AttnOutArgs a = {w.P, lin_q, hu, ldhu, w.kv, o, c.S, w.G, E, o16};
         launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
     }
 }
@@ -185,16 +186,17 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
 
 // bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
 // and the 8-step residual chain of h); statistics, gates and the outer residual stream x stay fp32.
-static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
+// x16: optional bf16 image of x (read by the two projections of x, rewritten with the block's result).
+static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C) {
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
-        a.bias = lw.b_gg; a.act = 2;
+        a.bias = lw.b_gg; a.act = 2; a.A16 = x16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
     {
         ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, nullptr, C);
-        a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a;
+        a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a; a.A16 = x16;
         launch_proj<A_PLAIN, EPI_NORM>(c, a);
     }
     unsigned short* h16 = w.h16a;
@@ -213,13 +215,13 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, const msf
     }
     {
         ProjArgs a = proj_args(nullptr, C, lw.w_po, C, C, c.S, x, C);
-        a.A16 = h16; a.bias = lw.b_po; a.res = x; a.ldr = C;
+        a.A16 = h16; a.bias = lw.b_po; a.res = x; a.ldr = C; a.out16 = x16;
         launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
     }
 }
 
-static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, const msf2_layer_weights& lw, int C) {
-    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, lw, C); return; }
+static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C) {
+    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, x16, lw, C); return; }
     // g = sigmoid(x Wgg^T + b)
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
@@ -268,6 +270,7 @@ static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, floa
 // ---- whole forward ----------------------------------------------------------
 struct FwdWs {
     float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv, *zeros;
+    unsigned short *x16, *o16;           // bf16 mode: operand images of the residual stream and the attention output
     AttnWs at;
     TcnWs tc;
     int nblk_enc, nblk_ln;
@@ -292,6 +295,11 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
     w.zeros = ar.take<float>(64);
+    w.x16 = w.o16 = nullptr;
+    if (cfg.precision == MSF2_PREC_BF16) {
+        w.x16 = ar.take<unsigned short>(M * C);
+        w.o16 = ar.take<unsigned short>(M * E);
+    }
     w.at = attn_ws(ar, B, S, E);
     w.tc = tcn_ws(ar, B, S, C, cfg.precision);
     return w;
@@ -390,7 +398,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     hipLaunchKernelGGL(posenc_kernel, dim3(cdiv((long)S * (C / 2), 256)), dim3(256), 0, c.st, wt->pe_inv_freq, wt->pe_scale, w.pe, S, C);
     {   // x = skip = GroupNorm(enc) Wce^T + pos_enc
         ProjArgs a = proj_args(w.enc, C, wt->w_ce, C, C, S, w.x, C);
-        a.out2 = w.skip; a.bstat = w.bstat; a.c1 = wt->c1_ce; a.c2 = wt->c2_ce; a.pe = w.pe;
+        a.out2 = w.skip; a.bstat = w.bstat; a.c1 = wt->c1_ce; a.c2 = wt->c2_ce; a.pe = w.pe; a.out16 = w.x16;
         launch_proj<A_PLAIN, EPI_NORM>(c, a);
     }
     copy_tap(c, tp.enc, w.enc, MC);
@@ -402,21 +410,21 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         launch_rowstat<0>(c, w.x, C, w.rowstat, C, 1, 0.f);
         {   // [v | u | qk] = silu(ScaleNorm(shift(x)) W^T + b)
             ProjArgs a = proj_args(w.x, C, lw.w_hq, C, NH, S, w.hu_pre, NH);
-            a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1; a.zeros = w.zeros;
+            a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1; a.zeros = w.zeros; a.A16 = w.x16;
             launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
         }
         launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
-        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E);
+        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E, w.o16);
         launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
         {   // to_out projection
             ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);
-            a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1;
+            a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16;
             launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
         }
-        launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1);   // x += po + dwconv17(po)
+        launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16);   // x += po + dwconv17(po)
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
         // ---- GatedTCNBlock ----
-        run_gated_tcn(c, w.tc, w.x, lw, C);
+        run_gated_tcn(c, w.tc, w.x, w.x16, lw, C);
         if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);
     }
 
@@ -537,7 +545,7 @@ int msf2_gated_tcn(float* x, const msf2_layer_weights* lw, int B, int S, int C, 
     TcnWs w = tcn_ws(ar, B, S, C, precision);
     if (!ar.ok()) return MSF2_ERR_WORKSPACE;
     Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S, precision};
-    run_gated_tcn(c, w, x, *lw, C);
+    run_gated_tcn(c, w, x, nullptr, *lw, C);
     return check_launch();
 }
 

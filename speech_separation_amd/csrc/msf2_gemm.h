@@ -652,6 +652,7 @@ struct AttnOutArgs {
     const float* kv;                 // [B][128][2E]
     float* o;                        // [B*S][E]
     int S, G, E;
+    unsigned short* o16;             // optional bf16 copy of o
 };
 struct AttnOut {
     typedef AttnOutArgs Args;
@@ -714,7 +715,11 @@ struct AttnOut {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
-                    if (ok[reg]) stg_off(a.o, mrow[reg] * e4 + j4, (au * v[tn][reg]) * sigmoid_f(av * u[tn][reg]));
+                    if (ok[reg]) {
+                        const float r = (au * v[tn][reg]) * sigmoid_f(av * u[tn][reg]);
+                        stg_off(a.o, mrow[reg] * e4 + j4, r);
+                        if (a.o16) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.o16) + ((mrow[reg] * e4 + j4) >> 1)) = (unsigned short)pk_bf16_1(r);
+                    }
                 }
             }
         }

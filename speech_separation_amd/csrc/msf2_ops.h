@@ -139,10 +139,11 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const float* __restrict__ 
 }
 
 // ---- ConvModule: y = x + dwconv17(x) along time (zero padded) ---------------
-// grid (ceil(C/4 / 128), ceil(S/TS), B), block 128, TS = 16.  dw: [17][C]
+// grid (ceil(C/4 / 128), ceil(S/TS), B), block 128, TS = 16.  dw: [17][C]; y16: optional bf16 copy of y
 constexpr int DW_TS = 16;
 __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dw,
-                                                       float* __restrict__ y, int ldy, int S, int C, int accumulate) {
+                                                       float* __restrict__ y, int ldy, int S, int C, int accumulate,
+                                                       unsigned short* __restrict__ y16) {
     const int cq = blockIdx.x * 128 + threadIdx.x;
     if (cq >= (C >> 2)) return;
     const int b = blockIdx.z, s0 = blockIdx.y * DW_TS;
@@ -179,6 +180,12 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
                 v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
             }
             *reinterpret_cast<float4*>(yb + (long)s * ldy) = v;
+            if (y16) {   // bf16 image of the result (pitch ldy) for the contractions that read it next
+                uint2 h;
+                h.x = pk_bf16_pair(v.x, v.y);
+                h.y = pk_bf16_pair(v.z, v.w);
+                *reinterpret_cast<uint2*>(y16 + ((long)b * S + s) * ldy + 4 * cq) = h;
+            }
         }
     }
 }
