@@ -108,6 +108,11 @@ static void launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* 
     hipLaunchKernelGGL(dwconv17_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16);
 }
 
+static void launch_dwconv17_bf16(const Ctx& c, const unsigned short* x, int ldx, const float* dw, unsigned short* y, int ldy, int C) {
+    dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
+    hipLaunchKernelGGL(dwconv17_bf16_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C);
+}
+
 // ---- FLASH attention core ---------------------------------------------------
 struct AttnWs {
     float *q4, *P, *part, *kv;
@@ -133,16 +138,23 @@ static AttnWs attn_ws(Arena& ar, int B, int S, int E) {
     return w;
 }
 static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ldhu, const float* gamma,
-                          const float* beta, const float* freqs, float* o, int E, unsigned short* o16 = nullptr) {
+                          const float* beta, const float* freqs, float* o, int E, unsigned short* o16 = nullptr,
+                          const unsigned short* hu16 = nullptr) {
+    // hu16 (bf16 mode): the hidden tensor [v | u | qk] is read as bf16 from there instead of fp32 from hu
     const long M = c.M;
-    hipLaunchKernelGGL(qk_prep_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, hu + 2 * E, ldhu, gamma, beta, freqs, w.q4, M, c.S);
+    if (hu16)
+        hipLaunchKernelGGL(qk_prep_kernel<true>, dim3(cdiv(M, 4)), dim3(256), 0, c.st, (const void*)(hu16 + 2 * E), ldhu, gamma, beta, freqs, w.q4, M, c.S);
+    else
+        hipLaunchKernelGGL(qk_prep_kernel<false>, dim3(cdiv(M, 4)), dim3(256), 0, c.st, (const void*)(hu + 2 * E), ldhu, gamma, beta, freqs, w.q4, M, c.S);
+    const float* hsrc = hu16 ? reinterpret_cast<const float*>(hu16) : hu;
     const float* quad_q = w.q4;
     const float* lin_q = w.q4 + 1 * M * MSF2_QK_DIM;
     const float* quad_k = w.q4 + 2 * M * MSF2_QK_DIM;
     const float* lin_k = w.q4 + 3 * M * MSF2_QK_DIM;
     {
-        LinKVArgs a = {lin_k, hu, ldhu, w.part, c.S, 2 * E, w.chunk};
-        launch_gemm<LinKV>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
+        LinKVArgs a = {lin_k, hsrc, ldhu, w.part, c.S, 2 * E, w.chunk};
+        if (hu16) launch_gemm<LinKVT<true>>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
+        else launch_gemm<LinKV>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
         const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
     }
@@ -151,8 +163,9 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
         launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
     }
     {
-        AttnOutArgs a = {w.P, lin_q, hu, ldhu, w.kv, o, c.S, w.G, E, o16};
-        launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
+        AttnOutArgs a = {w.P, lin_q, hsrc, ldhu, w.kv, o, c.S, w.G, E, o16};
+        if (hu16) launch_gemm<AttnOutT<true>>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
+        else launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
     }
 }
 
@@ -271,6 +284,7 @@ static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, floa
 struct FwdWs {
     float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv, *zeros;
     unsigned short *x16, *o16;           // bf16 mode: operand images of the residual stream and the attention output
+    unsigned short *hu_pre16, *hu16;     // bf16 mode: the hidden tensor before / after its ConvModule lives in bf16 only
     AttnWs at;
     TcnWs tc;
     int nblk_enc, nblk_ln;
@@ -295,8 +309,10 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
     w.zeros = ar.take<float>(64);
-    w.x16 = w.o16 = nullptr;
+    w.x16 = w.o16 = w.hu_pre16 = w.hu16 = nullptr;
     if (cfg.precision == MSF2_PREC_BF16) {
+        w.hu_pre16 = ar.take<unsigned short>(M * NH);
+        w.hu16 = ar.take<unsigned short>(M * NH);
         w.x16 = ar.take<unsigned short>(M * C);
         w.o16 = ar.take<unsigned short>(M * E);
     }
@@ -411,10 +427,12 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         {   // [v | u | qk] = silu(ScaleNorm(shift(x)) W^T + b)
             ProjArgs a = proj_args(w.x, C, lw.w_hq, C, NH, S, w.hu_pre, NH);
             a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1; a.zeros = w.zeros; a.A16 = w.x16;
+            if (w.hu_pre16) { a.out = nullptr; a.out16 = w.hu_pre16; }
             launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
         }
-        launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
-        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E, w.o16);
+        if (w.hu16) launch_dwconv17_bf16(c, w.hu_pre16, NH, lw.dw_hq, w.hu16, NH, NH);
+        else launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
+        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E, w.o16, w.hu16);
         launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
         {   // to_out projection
             ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);

@@ -597,7 +597,8 @@ struct LinKVArgs {
     float* part;                     // [B][nsplit][128][N]
     int S, N, chunk;
 };
-struct LinKV {
+template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
+struct LinKVT {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
     static constexpr bool B_BF16 = false;
@@ -620,7 +621,9 @@ struct LinKV {
     __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int s = k0 + kt * BK + ko;
         const float m = s < k1 ? 1.f : 0.f;
-        return mul4(ld4(a.hu + ((long)b * a.S + min(s, k1 - 1)) * a.ldhu + n0 + c), m);
+        const long off = ((long)b * a.S + min(s, k1 - 1)) * a.ldhu + n0 + c;
+        if constexpr (HU16) return mul4(ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu) + off, 0u), m);
+        else return mul4(ld4(a.hu + off), m);
     }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
@@ -638,6 +641,8 @@ struct LinKV {
     }
 };
 
+typedef LinKVT<false> LinKV;
+
 // ---------------------------------------------------------------------------
 // Attention output and gating for one half-group (128 query frames) and 64
 // value columns (v and u halves side by side in the B tile):
@@ -654,7 +659,8 @@ struct AttnOutArgs {
     int S, G, E;
     unsigned short* o16;             // optional bf16 copy of o
 };
-struct AttnOut {
+template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
+struct AttnOutT {
     typedef AttnOutArgs Args;
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
     static constexpr bool B_BF16 = false;
@@ -681,10 +687,17 @@ struct AttnOut {
     __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
         const int s = g * MSF2_GROUP + kt * BK + ko;
-        const float* pq = a.hu + ((long)b * a.S + min(s, a.S - 1)) * a.ldhu + e;
+        const long oq = ((long)b * a.S + min(s, a.S - 1)) * a.ldhu + e;
         const float* pl = a.kv + ((long)b * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko) * (2 * a.E) + e;
         const float m = (kt < KT_QUAD && s >= a.S) ? 0.f : 1.f;   // value rows past the utterance end are zero
-        return mul4(ld4(kt < KT_QUAD ? pq : pl), m);
+        if constexpr (HU16) {
+            // kt is wave-uniform: one of the two loads is issued from a valid dummy address and discarded
+            const float4 q = ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu) + (kt < KT_QUAD ? oq : 0), 0u);
+            const float4 l = ld4(kt < KT_QUAD ? a.kv : pl);
+            return mul4(kt < KT_QUAD ? q : l, m);
+        } else {
+            return mul4(ld4(kt < KT_QUAD ? a.hu + oq : pl), m);
+        }
     }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
@@ -705,8 +718,14 @@ struct AttnOut {
                 const unsigned j4 = 4u * (j0 + MSF2_ACC_COL(wc, TN, tn, lane));
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    v[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + j4);
-                    u[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + e4 + j4);
+                    if constexpr (HU16) {
+                        const char* h16 = reinterpret_cast<const char*>(a.hu);
+                        v[tn][reg] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(h16 + ((mrow[reg] * ldh4 + j4) >> 1)) << 16);
+                        u[tn][reg] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(h16 + ((mrow[reg] * ldh4 + e4 + j4) >> 1)) << 16);
+                    } else {
+                        v[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + j4);
+                        u[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + e4 + j4);
+                    }
                 }
             }
 #pragma unroll
@@ -725,5 +744,7 @@ struct AttnOut {
         }
     }
 };
+
+typedef AttnOutT<false> AttnOut;
 
 }  // namespace msf2

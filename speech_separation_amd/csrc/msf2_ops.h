@@ -157,8 +157,11 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
 #pragma unroll
     for (int r = -8; r < DW_TS + 8; ++r) {
         const int s = s0 + r;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s >= 0 && s < S) xv = *reinterpret_cast<const float4*>(xb + (long)s * ldx);
+        // unconditional load from the clamped row, zeroed by a 0/1 factor: a predicated load makes
+        // hipcc branch around it and wait for it on the spot, which serialises the 32 row loads
+        const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
+        float4 xv = *reinterpret_cast<const float4*>(xb + (long)min(max(s, 0), S - 1) * ldx);
+        xv.x *= inb; xv.y *= inb; xv.z *= inb; xv.w *= inb;
 #pragma unroll
         for (int o = 0; o < DW_TS; ++o) {
             const int k = r - o + 8;
@@ -190,17 +193,74 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
     }
 }
 
+// bf16 in, bf16 out (bf16 mode keeps the [M, 4C + 128] hidden tensor in bf16 on both sides of the
+// ConvModule); arithmetic in fp32.  Same grid and tiling as dwconv17_kernel, 8-byte accesses.
+__device__ __forceinline__ float4 bf16x4_ld(const unsigned short* p) {
+    const uint2 h = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                       __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+}
+__global__ __launch_bounds__(128) void dwconv17_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
+                                                            const float* __restrict__ dw, unsigned short* __restrict__ y,
+                                                            int ldy, int S, int C) {
+    const int cq = blockIdx.x * 128 + threadIdx.x;
+    if (cq >= (C >> 2)) return;
+    const int b = blockIdx.z, s0 = blockIdx.y * DW_TS;
+    float4 w[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) w[k] = *reinterpret_cast<const float4*>(dw + k * C + 4 * cq);
+    float4 acc[DW_TS];
+#pragma unroll
+    for (int o = 0; o < DW_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned short* xb = x + (long)b * S * ldx + 4 * cq;
+#pragma unroll
+    for (int r = -8; r < DW_TS + 8; ++r) {
+        const int s = s0 + r;
+        const float inb = (s >= 0 && s < S) ? 1.f : 0.f;      // see dwconv17_kernel
+        float4 xv = bf16x4_ld(xb + (long)min(max(s, 0), S - 1) * ldx);
+        xv.x *= inb; xv.y *= inb; xv.z *= inb; xv.w *= inb;
+#pragma unroll
+        for (int o = 0; o < DW_TS; ++o) {
+            const int k = r - o + 8;
+            if (k >= 0 && k < 17) {
+                acc[o].x += w[k].x * xv.x; acc[o].y += w[k].y * xv.y;
+                acc[o].z += w[k].z * xv.z; acc[o].w += w[k].w * xv.w;
+            }
+            if (r == o) { acc[o].x += xv.x; acc[o].y += xv.y; acc[o].z += xv.z; acc[o].w += xv.w; }
+        }
+    }
+    unsigned short* yb = y + (long)b * S * ldy + 4 * cq;
+#pragma unroll
+    for (int o = 0; o < DW_TS; ++o) {
+        const int s = s0 + o;
+        if (s < S) {
+            uint2 h;
+            h.x = pk_bf16_pair(acc[o].x, acc[o].y);
+            h.y = pk_bf16_pair(acc[o].z, acc[o].w);
+            *reinterpret_cast<uint2*>(yb + (long)s * ldy) = h;
+        }
+    }
+}
+
 // ---- OffsetScale + rotary -> quad_q/256, lin_q, quad_k, lin_k ----------------
 // qk: [M] rows, row stride ld (already offset to the qk columns).  q4: [4][M][128].
 // grid ceil(M/4), block 256 (64 lanes = 64 feature pairs of one row)
-__global__ __launch_bounds__(256) void qk_prep_kernel(const float* __restrict__ qk, int ld,
+// IN16: qk points at bf16 values (same indexing).
+template <bool IN16>
+__global__ __launch_bounds__(256) void qk_prep_kernel(const void* __restrict__ qk_, int ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ freqs, float* __restrict__ q4,
                                                       long M, int S) {
     const int p = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    const float2 x = *reinterpret_cast<const float2*>(qk + m * ld + 2 * p);
+    float2 x;
+    if constexpr (IN16) {
+        const unsigned h = *reinterpret_cast<const unsigned*>(static_cast<const unsigned short*>(qk_) + m * ld + 2 * p);
+        x = make_float2(__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u));
+    } else {
+        x = *reinterpret_cast<const float2*>(static_cast<const float*>(qk_) + m * ld + 2 * p);
+    }
     float c = 1.f, sn = 0.f;
     if (p < 16) {
         const float ang = (float)(m % S) * freqs[p];
