@@ -197,6 +197,16 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     return w;
 }
 
+static void launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned short* h16, const msf2_tcn_weights& tw, int C, int dil) {
+    const dim3 grid(w.nblk, c.B), blk(256);
+    switch (C) {   // frames per thread = 32 / (256 / (C / 8))
+        case 512: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<8>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        case 256: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<4>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        case 128: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<2>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        default:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<1>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+    }
+}
+
 // bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
 // and the 8-step residual chain of h); statistics, gates and the outer residual stream x stay fp32.
 // x16: optional bf16 image of x (read by the two projections of x, rewritten with the block's result).
@@ -216,8 +226,7 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned 
     unsigned short* hn16 = w.h16b;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, (const float*)nullptr, h16,
-                           tw.dw_w, tw.dw_b, (float*)nullptr, w.t16, w.part, c.S, C, 1 << j, TCN_TS);
+        launch_stage_a_bf16(c, w, h16, tw, C, 1 << j);
         launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
@@ -432,8 +441,13 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         }
         if (w.hu16) launch_dwconv17_bf16(c, w.hu_pre16, NH, lw.dw_hq, w.hu16, NH, NH);
         else launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
-        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o, E, w.o16, w.hu16);
-        launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
+        // bf16 mode: the attention output exists only as the bf16 image its projection reads
+        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o16 ? nullptr : w.o, E, w.o16, w.hu16);
+        if (w.o16)
+            hipLaunchKernelGGL((rowstat_kernel<0, true>), dim3(cdiv(c.M, 4)), dim3(256), 0, c.st,
+                               reinterpret_cast<const float*>(w.o16), E, w.rowstat, c.M, c.S, E, 0, 0.f);
+        else
+            launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
         {   // to_out projection
             ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);
             a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16;

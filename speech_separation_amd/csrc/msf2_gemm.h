@@ -655,7 +655,7 @@ struct AttnOutArgs {
     const float* lq;                 // [B*S][128]
     const float* hu;  int ldhu;      // v | u | ...
     const float* kv;                 // [B][128][2E]
-    float* o;                        // [B*S][E]
+    float* o;                        // [B*S][E]; may be null when o16 is given
     int S, G, E;
     unsigned short* o16;             // optional bf16 copy of o
 };
@@ -736,7 +736,7 @@ struct AttnOutT {
                     const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
                     if (ok[reg]) {
                         const float r = (au * v[tn][reg]) * sigmoid_f(av * u[tn][reg]);
-                        stg_off(a.o, mrow[reg] * e4 + j4, r);
+                        if (a.o) stg_off(a.o, mrow[reg] * e4 + j4, r);
                         if (a.o16) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.o16) + ((mrow[reg] * e4 + j4) >> 1)) = (unsigned short)pk_bf16_1(r);
                     }
                 }

@@ -92,7 +92,8 @@ __global__ void posenc_kernel(const float* __restrict__ inv_freq, float scale, f
 //         (optionally token-shifted) row -> out[m]
 // MODE 1: LayerNorm (mean, rstd) -> out[2m], out[2m+1]
 // grid ceil(M/4), block 256.  C <= 1024.
-template <int MODE>
+// IN16: x points at bf16 values (same indexing).
+template <int MODE, bool IN16 = false>
 __global__ __launch_bounds__(256) void rowstat_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
                                                       long M, int S, int C, int shift, float eps) {
     const int lane = threadIdx.x & 63;
@@ -112,7 +113,15 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const float* __restrict__ 
                 if (m % S == 0) zero = true;
                 row = m - 1;
             }
-            if (!zero) v[i] = *reinterpret_cast<const float4*>(x + row * ldx + 4 * q);
+            if (!zero) {
+                if constexpr (IN16) {
+                    const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + row * ldx + 4 * q);
+                    v[i] = make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                                       __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+                } else {
+                    v[i] = *reinterpret_cast<const float4*>(x + row * ldx + 4 * q);
+                }
+            }
         }
         sum += v[i].x + v[i].y + v[i].z + v[i].w;
         ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
@@ -342,6 +351,70 @@ __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restric
         }
         sum += v.x + v.y + v.z + v.w;
         sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
+}
+
+// bf16 in / bf16 out form of stage A for the bf16 mode: 8 channels (16 bytes) per lane, the
+// NIT frames of a thread fully unrolled with all 3 * NIT row loads issued up front from clamped
+// rows (taps outside the utterance are zeroed by a 0/1 factor, never by a predicated load).
+// grid (ceil(S/32), B), block 256, NIT = 32 / (256 / (C/8)).  Statistics from the fp32 values.
+template <int NIT>
+__global__ __launch_bounds__(256) void tcn_stage_a_bf16_kernel(const unsigned short* __restrict__ h16, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, unsigned short* __restrict__ t16,
+                                                               float* __restrict__ part, int S, int C, int dil) {
+    __shared__ float red[8];
+    const int lpf = C >> 3, cq = threadIdx.x % lpf, fo = threadIdx.x / lpf, nf = 256 / lpf;
+    const int b = blockIdx.y, s0 = blockIdx.x * 32;
+    const int c = 8 * cq;
+    float wk[3][8], bs[8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 lo = *reinterpret_cast<const float4*>(w + k * C + c), hi = *reinterpret_cast<const float4*>(w + k * C + c + 4);
+        wk[k][0] = lo.x; wk[k][1] = lo.y; wk[k][2] = lo.z; wk[k][3] = lo.w;
+        wk[k][4] = hi.x; wk[k][5] = hi.y; wk[k][6] = hi.z; wk[k][7] = hi.w;
+    }
+    {
+        const float4 lo = *reinterpret_cast<const float4*>(bias + c), hi = *reinterpret_cast<const float4*>(bias + c + 4);
+        bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
+    }
+    const unsigned short* hb = h16 + (long)b * S * C + c;
+    uint4 xm[NIT], x0[NIT], xp[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = min(s0 + fo + nf * i, S - 1);
+        xm[i] = *reinterpret_cast<const uint4*>(hb + (long)max(s - dil, 0) * C);
+        x0[i] = *reinterpret_cast<const uint4*>(hb + (long)s * C);
+        xp[i] = *reinterpret_cast<const uint4*>(hb + (long)min(s + dil, S - 1) * C);
+    }
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int s = s0 + fo + nf * i;
+        const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
+        const unsigned am[4] = {xm[i].x, xm[i].y, xm[i].z, xm[i].w};
+        const unsigned a0[4] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w};
+        const unsigned ap[4] = {xp[i].x, xp[i].y, xp[i].z, xp[i].w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int hbit = 0; hbit < 2; ++hbit) {
+                const int e = 2 * j + hbit;
+                const float m_ = __builtin_bit_cast(float, hbit ? (am[j] & 0xffff0000u) : (am[j] << 16)) * fm;
+                const float z_ = __builtin_bit_cast(float, hbit ? (a0[j] & 0xffff0000u) : (a0[j] << 16));
+                const float p_ = __builtin_bit_cast(float, hbit ? (ap[j] & 0xffff0000u) : (ap[j] << 16)) * fp;
+                v[e] = silu_f(wk[0][e] * m_ + wk[1][e] * z_ + wk[2][e] * p_ + bs[e]);
+            }
+        }
+        if (s < S) {
+            uint4 pk;
+            pk.x = pk_bf16_pair(v[0], v[1]); pk.y = pk_bf16_pair(v[2], v[3]);
+            pk.z = pk_bf16_pair(v[4], v[5]); pk.w = pk_bf16_pair(v[6], v[7]);
+            *reinterpret_cast<uint4*>(t16 + ((long)b * S + s) * C + c) = pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sum += v[e]; sq += v[e] * v[e]; }
+        }
     }
     write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
 }
