@@ -74,15 +74,34 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
     }
     const TimedLaunch timed_(EPI == EPI_TCN ? c.st : nullptr, EPI == EPI_TCN);
     if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16)) {
-        // one workgroup walks several column tiles of its row tile as long as that still
-        // leaves at least two full rounds of workgroups (512 resident at 2 per CU)
-        int loop = grid.x;
+        // One workgroup walks 2 column tiles of its row tile: its ring then prefetches the second tile
+        // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
+        // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all
+        // 4 tiles re-reads A from the fabric 4 times (FETCH_SIZE 2.4 GB instead of 0.9 GB per launch).
+        int loop = 2;
         if (const char* e = getenv("MSF2_NCOL_LOOP")) loop = atoi(e) > 0 ? atoi(e) : 1;
-        while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
         ProjArgs al = a;
+        if constexpr (!P::PAIRED) {
+            // 256-row tiles, one 8-wave workgroup per CU, when that still gives every CU several tiles
+            typedef DmaGeom<P, 1> G;
+            dim3 gb(cdiv(a.N, G::BNX), cdiv(c.S, G::BMX), c.B);
+            // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 2 % slower for the
+            // two-product TCN contraction and the N = 2176 projection, which keep the 128 x 128 form
+            const bool want = P::NSEG == 1 && a.N <= 1024 && getenv("MSF2_NO_BIG") == nullptr;
+            if (want && (long)gb.x * gb.y * gb.z >= 1024) {
+                int lb = loop > (int)gb.x ? (int)gb.x : loop;
+                if (P::NSEG == 1) lb = 1;         // 256 columns per tile already
+                al.ncol_loop = lb;
+                gb.x = cdiv(gb.x, lb);
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);
+                return;
+            }
+        }
+        if (loop > (int)grid.x) loop = grid.x;
+        while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
         al.ncol_loop = loop;
         grid.x = cdiv(grid.x, loop);
-        hipLaunchKernelGGL(gemm_kernel_bf16_dma<P>, grid, dim3(256), 0, c.st, al);
+        hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 0>), grid, dim3(256), 0, c.st, al);
     } else
         launch_gemm<P>(c, grid, a);
 }

@@ -353,9 +353,18 @@ struct ProjNT {
         s0 = (rest % gridDim.y) * BM;
         n0 = nt * (a.ncol_loop > 1 ? a.ncol_loop : 1) * NW;
     }
-    static constexpr int NW = PAIRED ? BN / 2 : BN;     // output columns one tile covers
-    __device__ int col_tiles_here() const {            // tiles this workgroup walks (DMA kernel)
-        const int left = (a.N - n0 + NW - 1) / NW;
+    static constexpr int NW = PAIRED ? BN / 2 : BN;     // output columns one 128-wide tile covers
+    // workgroup -> tile for kernels with their own tile shape: tbm rows x tbn columns per tile
+    __device__ void init_tile(const Args& args, int tbm, int tbn) {
+        a = args;
+        const unsigned t = xcd_remap();
+        const unsigned nt = t % gridDim.x, rest = t / gridDim.x;
+        b = rest / gridDim.y;
+        s0 = (rest % gridDim.y) * tbm;
+        n0 = nt * (a.ncol_loop > 1 ? a.ncol_loop : 1) * tbn;
+    }
+    __device__ int col_tiles_here(int nw) const {      // tiles of nw columns this workgroup walks (DMA kernel)
+        const int left = (a.N - n0 + nw - 1) / nw;
         return min(a.ncol_loop > 1 ? a.ncol_loop : 1, left);
     }
     __device__ int nk(int) const { return a.K / BK; }

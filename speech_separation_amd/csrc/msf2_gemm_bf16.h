@@ -180,11 +180,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Arg
 // Both K segments of a two-accumulator problem run through one continuous ring.
 // One wave instruction moves 16 rows x 64 B; the swizzle is on the source address.
 // ---------------------------------------------------------------------------
-template <class P, bool IS_A>
+// Workgroup geometry of the DMA kernel.
+//   BIG = 0: 128 x 128 tile, 4 waves, 2 workgroups per CU.
+//   BIG = 1: 256 x 128 (two products) or 256 x 256 (one product) tile, 8 waves as 4 x 2, ONE workgroup per
+//            CU (still 2 waves per SIMD, 256 registers each).  Per MFMA it moves 0.75x / 0.5x the bytes
+//            from L2 into LDS: at 17 B/clk per CU the 128 x 128 form sits at the ceiling of what one CU's
+//            load path delivers (nothing else is saturated: MFMA busy 21 %, LDS reads 20 %, HBM 35 %).
+template <class P, int BIG> struct DmaGeom;
+template <class P> struct DmaGeom<P, 0> {
+    static constexpr int THREADS = 256, WR = P::WR, WC = P::WC, BMX = BM, BNX = BN;
+    static constexpr int TM = BM / (32 * WR), TN = BN / (32 * WC), NWX = P::NW, NST = 4, MINB = 2;
+};
+template <class P> struct DmaGeom<P, 1> {
+    static constexpr int THREADS = 512, WR = 4, WC = 2, TM = 2, TN = (P::NSEG == 2) ? 2 : 4;
+    static constexpr int BMX = 256, BNX = WC * TN * 32, NWX = BNX, NST = 4, MINB = 1;
+};
+
+// rows x 32 k of one operand: 16 rows x 64 B per wave instruction, shared evenly by the waves
+template <class P, bool IS_A, int ROWS, int NWAVES>
 __device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, int kt, int wave, int lane) {
+    constexpr int PER_WAVE = ROWS / 16 / NWAVES;
+    static_assert(PER_WAVE >= 1 && PER_WAVE * 16 * NWAVES == ROWS, "tile rows must split evenly over the waves");
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int inst = wave * 2 + i;
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wave * PER_WAVE + i;
         const int row = inst * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ bf_swz(row);
         const unsigned short* src;
@@ -197,32 +216,35 @@ __device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, 
     }
 }
 
-template <class P>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
-    constexpr int NST = 4;
-    __shared__ __attribute__((aligned(1024))) char sm[NST * 2 * BF_TILE + 4 * 4096];   // ring + one 4 KiB epilogue tile per wave
+template <class P, int BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
+    typedef DmaGeom<P, BIG> G;
+    static_assert(BIG == 0 || !P::PAIRED, "paired-column problems keep the 128 x 128 geometry");
+    constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
+    constexpr int TILE_A = G::BMX * 64, TILE_B = G::BNX * 64, STAGE = TILE_A + TILE_B;   // bytes
+    constexpr int DMA_PER_TILE = (G::BMX + G::BNX) / 16 / NWAVES;                         // copies per wave and k tile
+    __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + NWAVES * 4096];      // ring + one 4 KiB epilogue tile per wave
     P prob;
-    prob.init(args);
+    if constexpr (BIG) prob.init_tile(args, G::BMX, G::NWX);
+    else prob.init(args);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / P::WC, wc = wave % P::WC;
-    constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
+    const int wr = wave / G::WC, wc = wave % G::WC;
     // A workgroup walks `nrep` consecutive column tiles of its row tile; the k tiles of all of
     // them form one continuous stream through the ring, so the first tiles of the next column
-    // tile are already in flight while the epilogue of the current one runs, and the A rows are
-    // re-read out of L2 instead of four workgroups missing on them at the same moment.
+    // tile are already in flight while the epilogue of the current one runs.
     const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG;
-    const int nrep = prob.col_tiles_here();
+    const int nrep = prob.col_tiles_here(G::NWX);
     const int total = nrep * nkt;
     P pf = prob;                 // the prefetch position runs NST-1 tiles ahead of the consumer
     int pf_t = 0, issued = 0;
     auto issue = [&]() {
         const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
         const int kt = pf_t - seg * nk0;
-        char* base = sm + (issued & (NST - 1)) * 2 * BF_TILE;
-        bf_dma_tile<P, true>(pf, base, seg, kt, wave, lane);
-        bf_dma_tile<P, false>(pf, base + BF_TILE, seg, kt, wave, lane);
+        char* base = sm + (issued & (NST - 1)) * STAGE;
+        bf_dma_tile<P, true, G::BMX, NWAVES>(pf, base, seg, kt, wave, lane);
+        bf_dma_tile<P, false, G::BNX, NWAVES>(pf, base + TILE_A, seg, kt, wave, lane);
         ++issued;
-        if (++pf_t == nkt) { pf_t = 0; pf.n0 += P::NW; }
+        if (++pf_t == nkt) { pf_t = 0; pf.n0 += G::NWX; }
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
@@ -230,19 +252,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
     int cons = 0;                // tiles consumed so far (all column tiles)
+#ifdef MSF2_DIAG_STAMP
+    unsigned long long tq[5] = {0, 0, 0, 0, 0}, tepi = 0;
+    unsigned long long q0, q1, q2, q3, q4;
+#endif
     auto step = [&](bool fresh, f32x16 (&ac)[TM][TN]) {
         // tile `cons` has landed once at most the DMA instructions of the tiles issued after it
         // are outstanding; right after an epilogue its stores share the counter, so drain it all
         // (the tiles waited for were issued before the epilogue started)
         const int rem = total - 1 - cons;
+        MSF2_STAMP(q0)
         if (fresh || rem == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+        MSF2_STAMP(q1)
         __builtin_amdgcn_s_barrier();
-        if (issued < total) issue();                    // refills the slot every wave finished reading last step
-        __builtin_amdgcn_sched_barrier(0);
-        const char* sa = sm + (cons & (NST - 1)) * 2 * BF_TILE;
-        const char* sb = sa + BF_TILE;
+        MSF2_STAMP(q2)
+        // All fragment reads of the step go out first and stay in flight while the address arithmetic
+        // and the copies of the refill are issued; the MFMAs then start as their operands arrive.
+        const char* sa = sm + (cons & (NST - 1)) * STAGE;
+        const char* sb = sa + TILE_A;
         ++cons;
         bf16x8_t af[2][TM], bf[2][TN];
 #pragma unroll
@@ -252,6 +281,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
 #pragma unroll
             for (int q = 0; q < TN; ++q) bf[st][q] = bf_frag(sb, rowB + q * 32, st, kh);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (issued < total) issue();                    // refills the slot every wave finished reading last step
+        __builtin_amdgcn_sched_barrier(0);
+        MSF2_STAMP(q3)
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -260,7 +293,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
                 for (int tn = 0; tn < TN; ++tn)
                     ac[tm][tn] = P::ACC_T ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st][tn], af[st][tm], ac[tm][tn], 0, 0, 0)
                                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        MSF2_STAMP(q4)
+#ifdef MSF2_DIAG_STAMP
+        tq[0] += q1 - q0; tq[1] += q2 - q1; tq[2] += q3 - q2; tq[3] += q4 - q3; tq[4] += 1;
+#endif
     };
+#ifdef MSF2_DIAG_STAMP
+    unsigned long long e0 = 0, e1 = 0, e2 = 0;
+    MSF2_STAMP(e0)
+#endif
     for (int rep = 0; rep < nrep; ++rep) {
         f32x16 acc[P::NSEG][TM][TN];
 #pragma unroll
@@ -284,10 +326,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16_dma(const typename P:
             if (sum == 123.456f) sm[0] = (char)sum;
         }
 #else
-        prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(sm + NST * 2 * BF_TILE) + wave * 1024);
+        MSF2_STAMP(e1)
+        prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(sm + NST * STAGE) + wave * 1024);
+        MSF2_STAMP(e2)
+#ifdef MSF2_DIAG_STAMP
+        tepi += e2 - e1;
 #endif
-        prob.n0 += P::NW;
+#endif
+        prob.n0 += G::NWX;
     }
+#ifdef MSF2_DIAG_STAMP
+    MSF2_STAMP(e2)
+    if (lane == 0 && P::NSEG == 2) {     // per wave: vmcnt wait, barrier wait, reads + refill issue, MFMA issue, steps, epilogue, total
+        const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (L < 2048 && wave < 4) {
+            unsigned long long* o = g_stamp + (L * 4 + wave) * 4;
+            o[0] = tq[0]; o[1] = tq[1]; o[2] = tq[2]; o[3] = tq[3];
+            g_stamp2[(L * 4 + wave) * 2 + 0] = tq[4] | (tepi << 20);
+            g_stamp2[(L * 4 + wave) * 2 + 1] = e2 - e0;
+        }
+    }
+#endif
 }
 
 }  // namespace msf2
