@@ -19,17 +19,20 @@ import torch
 import torch.distributed as dist
 
 
-def make_work_items(lengths, max_batch):
+def make_work_items(lengths, max_batch, max_samples=None):
     """Group utterance indices by exact length, split groups into batches of at
-    most max_batch.  Returns [(length, [indices])], longest first."""
+    most max_batch utterances (and, if given, at most max_samples samples in
+    total, but never fewer than one utterance).  Returns [(length, [indices])],
+    longest first."""
     groups = defaultdict(list)
     for i, n in enumerate(lengths):
         groups[int(n)].append(i)
     items = []
     for n in sorted(groups, reverse=True):
         idx = groups[n]
-        for j in range(0, len(idx), max_batch):
-            items.append((n, idx[j:j + max_batch]))
+        step = max_batch if max_samples is None else max(1, min(max_batch, max_samples // n))
+        for j in range(0, len(idx), step):
+            items.append((n, idx[j:j + step]))
     return items
 
 
@@ -47,7 +50,7 @@ def assign_items(items, world):
 
 
 def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device="cpu",
-                     references=None, gather=True):
+                     references=None, gather=True, max_samples=None):
     """Separate a list of 1-D float32 utterances, sharded over ``world`` ranks.
 
     model_fn(x[B, T] tensor on device) -> list of num_spks tensors [B, T].
@@ -58,7 +61,7 @@ def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device
     """
     from .synth import permute_si_sdr
     lengths = [len(u) for u in utterances]
-    plan = assign_items(make_work_items(lengths, max_batch), world)
+    plan = assign_items(make_work_items(lengths, max_batch, max_samples), world)
     mine = plan[rank]
     local = {}
     for n, idx in mine:

@@ -301,6 +301,52 @@ def test_bf16_full_model_si_sdr(golden_dir):
     assert min(fid) >= 30.0
 
 
+def test_bf16_kernel_choices_agree():
+    """The bf16 projections pick their kernel by problem size (register-staged, 128 x 128 global->LDS ring with
+    1 or 2 column tiles per workgroup, 256-row 8-wave geometry).  Every choice performs the same arithmetic
+    in the same order per output element, so a gated TCN block at a size that enables all of them must
+    not depend on which one ran."""
+    g = torch.Generator().manual_seed(21)
+    B, S, C = 32, 3999, FULL_8K.dim
+    cfg1 = type(FULL_8K)(num_layers=1)
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(cfg1, 0).items()}
+    pk = PackedWeights(sd, cfg1, DEV, BF)
+    x = torch.randn(B, S, C, generator=g).to(DEV)
+    outs = {}
+    for name, env in (("default", {}), ("no_big", {"MSF2_NO_BIG": "1"}), ("loop1", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "1"}),
+                      ("loop4", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "4"})):
+        for k in ("MSF2_NO_BIG", "MSF2_NCOL_LOOP"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            outs[name] = ops.gated_tcn(x.clone(), pk.layers[0], precision=BF)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert torch.isfinite(outs["default"]).all()
+    for name in ("no_big", "loop1", "loop4"):
+        assert torch.equal(outs[name], outs["default"]), name
+
+
+def test_bf16_batch_independence():
+    """bf16 mode, full model: an utterance gives the same waveform alone and inside a batch of 12, up to
+    bf16 rounding noise: the linear-attention summary is split over time in a batch-dependent number of
+    chunks, the fp32 sums differ in their last bits, and in bf16 mode such bits flip roundings downstream.
+    Bound: the two waveforms agree to better than 35 dB (fp32 mode: 1e-5 of the peak, see
+    test_full_size_batch_properties)."""
+    from speech_separation_amd.synth import si_sdr
+    m = MossFormerHIP(FULL_8K, compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(FULL_8K, 0).items()})
+    x = torch.from_numpy(synth_batch(12, 32000, seed0=0)).to(DEV)
+    a = torch.stack(m(x), 0)
+    single = torch.stack(m(x[7:8]), 0)
+    peak = float(a.abs().max())
+    assert torch.isfinite(a).all()
+    assert float((a[:, 7:8] - single).abs().max()) <= 2e-2 * peak
+    for spk in range(2):
+        assert si_sdr(a[spk, 7].cpu().numpy(), single[spk, 0].cpu().numpy()) >= 35.0
+
+
 # -------------------------------------------------- size-independent properties
 def test_full_size_batch_properties(models):
     """At the benchmark size (16 x 4 s, 24 layers): utterances in a batch are
