@@ -73,7 +73,8 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         return;
     }
     const TimedLaunch timed_(EPI == EPI_TCN ? c.st : nullptr, EPI == EPI_TCN);
-    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || a.A2_16)) {
+    // (the two-product form of the DMA kernel streams the bf16 residual with the operands: it needs res16)
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || (a.A2_16 && a.res16))) {
         // One workgroup walks 2 column tiles of its row tile: its ring then prefetches the second tile
         // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
         // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all

@@ -338,6 +338,7 @@ template <int AMODE, int EPI>
 struct ProjNT {
     typedef ProjArgs Args;
     static constexpr bool PAIRED = (EPI == EPI_TANH_SIG);
+    static constexpr int EPI_KIND = EPI;
     static constexpr int WR = PAIRED ? 4 : 2, WC = PAIRED ? 1 : 2;
     static constexpr int NSEG = (EPI == EPI_TCN) ? 2 : 1;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
@@ -408,6 +409,11 @@ struct ProjNT {
         }
         return base + row * a.lda + k;
     }
+    // bf16 residual (a.res16, pitch ldr) of row r of this workgroup's tile, 8 columns from column n0 + c
+    __device__ const unsigned short* ptrRes16(int r, int c) const {
+        const int s = min(s0 + r, a.S - 1);
+        return a.res16 + ((long)b * a.S + s) * a.ldr + min(n0 + c, a.N - 8);
+    }
     // bf16 kernels: W / W2 point at bf16 weights [N][K]
     __device__ const unsigned short* ptrB16(int seg, int kt, int c, int ko) const {
         const float* w = a.W;
@@ -431,8 +437,10 @@ struct ProjNT {
     // byte offset (the host rejects buffers beyond 4 GiB and pointers that are not 16-byte aligned;
     // N is a multiple of 4).  LDS accesses of one wave execute in program order, so the two phases
     // need no barrier, only the compiler fence.
-    template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage) const {
+    // RESLDS: the bf16 residual of this wave's rows was copied into LDS with the operand stream (rtile: 64 rows
+    // x 128 columns, 256 B per row, 16-byte chunk c of row r at chunk position c ^ (r & 7)) and is read from there.
+    template <int TM, int TN, bool RESLDS = false>
+    __device__ void epilogue(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage, const char* rtile = nullptr) const {
         float mean_b = 0.f, rstd_b = 1.f;
         if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
         constexpr int TNE = PAIRED ? TN / 2 : TN;
@@ -473,8 +481,16 @@ struct ProjNT {
                 for (int i = 0; i < 4; ++i) {
                     rv[i] = zero4;
                     gv[i] = one4;
-                    if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
-                    if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                    if constexpr (RESLDS) {
+                        const int rrow = tm * 32 + 8 * i + rr;                   // row inside the wave's 64-row tile
+                        const int chunk = (wc * (TN * 4) + tn * 4 + (rc >> 1)) ^ (rrow & 7);
+                        const uint2 h = *reinterpret_cast<const uint2*>(rtile + rrow * 256 + chunk * 16 + (rc & 1) * 8);
+                        rv[i] = make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
+                                            __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
+                    } else {
+                        if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
+                        if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                    }
                     if (EPI == EPI_NORM && a.pe) rv[i] = ldg4_off(a.pe, (mrow[i] - m_base) * (4u * a.N) + nc4);
                     if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
                 }

@@ -232,39 +232,63 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     // A workgroup walks `nrep` consecutive column tiles of its row tile; the k tiles of all of
     // them form one continuous stream through the ring, so the first tiles of the next column
     // tile are already in flight while the epilogue of the current one runs.
-    const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG;
+    //
+    // RESLDS (the two-product TCN contraction): the bf16 residual tile of the epilogue (128 rows x 128
+    // columns = 2 ring stages of 64 rows x 256 B) rides the same stream as two extra tiles after the k
+    // tiles of each column tile and is read from LDS.  Loaded from global memory by the epilogue itself
+    // it queues behind the ~96 KB of operand copies the CU has in flight: those 16 loads cost more
+    // cycles than the 32 K steps.
+    constexpr bool RESLDS = (BIG == 0) && (P::EPI_KIND == EPI_TCN);
+    constexpr int NRES = RESLDS ? 2 : 0;
+    static_assert(!RESLDS || (STAGE == 16384 && DMA_PER_TILE == 4), "residual tiles reuse the ring stage and its copy count");
+    const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG, nstream = nkt + NRES;
     const int nrep = prob.col_tiles_here(G::NWX);
-    const int total = nrep * nkt;
+    const int total = nrep * nstream;
     P pf = prob;                 // the prefetch position runs NST-1 tiles ahead of the consumer
     int pf_t = 0, issued = 0;
     auto issue = [&]() {
-        const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
-        const int kt = pf_t - seg * nk0;
         char* base = sm + (issued & (NST - 1)) * STAGE;
-        bf_dma_tile<P, true, G::BMX, NWAVES>(pf, base, seg, kt, wave, lane);
-        bf_dma_tile<P, false, G::BNX, NWAVES>(pf, base + TILE_A, seg, kt, wave, lane);
+        if (RESLDS && pf_t >= nkt) {
+            // residual rows 64 r .. 64 r + 63: one copy = 4 rows x 256 B, chunk swizzled on the source side
+            const int r = pf_t - nkt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int inst = wave * 4 + i;
+                const int row = inst * 4 + (lane >> 4);
+                const int chunk = (lane & 15) ^ (row & 7);
+                dma16(pf.ptrRes16(64 * r + row, chunk * 8), __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+            }
+        } else {
+            const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
+            const int kt = pf_t - seg * nk0;
+            bf_dma_tile<P, true, G::BMX, NWAVES>(pf, base, seg, kt, wave, lane);
+            bf_dma_tile<P, false, G::BNX, NWAVES>(pf, base + TILE_A, seg, kt, wave, lane);
+        }
         ++issued;
-        if (++pf_t == nkt) { pf_t = 0; pf.n0 += G::NWX; }
+        if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }
+    };
+    // Tile `idx` has landed once at most the copies of the tiles issued after it are outstanding.  Loads,
+    // stores and copies retire in issue order, so epilogue stores issued in between only make this stricter.
+    auto wait_tile = [&](int idx) {
+        const int after = issued - idx - 1;
+        if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+        else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMA_PER_TILE) : "memory");
     };
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (issued < total) issue();
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
-    int cons = 0;                // tiles consumed so far (all column tiles)
+    int cons = 0;                // stream index of the next tile to consume (all column tiles)
 #ifdef MSF2_DIAG_STAMP
     unsigned long long tq[5] = {0, 0, 0, 0, 0}, tepi = 0;
     unsigned long long q0, q1, q2, q3, q4;
 #endif
-    auto step = [&](bool fresh, f32x16 (&ac)[TM][TN]) {
-        // tile `cons` has landed once at most the DMA instructions of the tiles issued after it
-        // are outstanding; right after an epilogue its stores share the counter, so drain it all
-        // (the tiles waited for were issued before the epilogue started)
-        const int rem = total - 1 - cons;
+    auto step = [&](f32x16 (&ac)[TM][TN]) {
         MSF2_STAMP(q0)
-        if (fresh || rem == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+        wait_tile(cons);
         MSF2_STAMP(q1)
         __builtin_amdgcn_s_barrier();
         MSF2_STAMP(q2)
@@ -303,6 +327,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     unsigned long long e0 = 0, e1 = 0, e2 = 0;
     MSF2_STAMP(e0)
 #endif
+    float* stage = reinterpret_cast<float*>(sm + NST * STAGE) + wave * 1024;
     for (int rep = 0; rep < nrep; ++rep) {
         f32x16 acc[P::NSEG][TM][TN];
 #pragma unroll
@@ -313,9 +338,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
-        for (int t = 0; t < nk0; ++t) step(rep > 0 && t == 0, acc[0]);
+        for (int t = 0; t < nk0; ++t) step(acc[0]);
         if constexpr (P::NSEG == 2)
-            for (int t = nk0; t < nkt; ++t) step(false, acc[1]);
+            for (int t = nk0; t < nkt; ++t) step(acc[1]);
 #ifdef MSF2_DIAG_NOEPI
         {   // timing-only build: keep the accumulators alive with one conditional store
             float sum = 0.f;
@@ -325,9 +350,27 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
                         for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
             if (sum == 123.456f) sm[0] = (char)sum;
         }
+        if constexpr (RESLDS) {
+            cons += NRES;
+            __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < NRES; ++i)
+                if (issued < total) issue();
+        }
 #else
         MSF2_STAMP(e1)
-        prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(sm + NST * STAGE) + wave * 1024);
+        if constexpr (RESLDS) {
+            // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
+            wait_tile(cons + 1);
+            __builtin_amdgcn_s_barrier();
+            prob.template epilogue<TM, TN, true>(acc, wr, wc, lane, stage, sm + ((cons + wr) & (NST - 1)) * STAGE);
+            cons += NRES;
+            // every wave is done with the residual stages (and with the last k tile): refill them
+            __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < NRES; ++i)
+                if (issued < total) issue();
+        } else {
+            prob.template epilogue<TM, TN>(acc, wr, wc, lane, stage);
+        }
         MSF2_STAMP(e2)
 #ifdef MSF2_DIAG_STAMP
         tepi += e2 - e1;
