@@ -376,3 +376,24 @@ def test_long_form_runs(models):
     assert out.shape == (2, 1, 492000)
     assert torch.isfinite(out).all()
     assert float(out.abs().max()) > 0
+
+
+def test_file_to_file_driver(golden_dir, tmp_path):
+    """inference.py's loop on a wav the reference ships: two 16-bit files of the input's length, peak normalised."""
+    import shutil
+    from types import SimpleNamespace
+    from speech_separation_amd import infer
+    from speech_separation_amd.wavio import read_wav
+    src = tmp_path / "in"
+    src.mkdir()
+    shutil.copy(os.path.join(golden_dir, "ref_input_nam_nam_8k.wav"), src / "mix.wav")
+    ns = SimpleNamespace(input_path=str(src), output_dir=str(tmp_path / "out"), checkpoint_dir=None, precision="fp32",
+                         one_time_decode_length=60, decode_window=1)
+    written = infer.run(ns)
+    assert [os.path.basename(p) for p in written] == ["mix_s1.wav", "mix_s2.wav"]
+    peaks = []
+    for p in written:
+        x, fs = read_wav(p)
+        assert fs == 8000 and x.shape == (24360,)
+        peaks.append(np.abs(x).max())
+    assert 0.2 < max(peaks) <= 1.0                  # joint peak normalisation over the padded length (reference: utils/decode.py:78-83)

@@ -160,3 +160,53 @@ def test_synth_mixture_shape_and_level():
     rms = np.sqrt((x ** 2).mean())
     assert 0.03 < rms < 0.2
     assert np.array_equal(x, synth_batch(2, 8000, seed0=0))
+
+
+# ------------------------------------------------------------------ wav I/O
+def test_wav_read_matches_pcm16_definition(golden_dir):
+    """A file the reference ships (outputs/clean/input): 16-bit mono 8 kHz, samples = int16 / 32768."""
+    import wave
+    from speech_separation_amd.wavio import audioread, read_wav
+    path = os.path.join(golden_dir, "ref_input_nam_nam_8k.wav")
+    x, fs = read_wav(path)
+    w = wave.open(path, "rb")
+    raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    w.close()
+    assert fs == 8000 and x.shape == (24360,) and x.dtype == np.float64
+    assert np.array_equal(x, raw.astype(np.float64) / 32768.0)
+    assert np.array_equal(audioread(path, 8000), x)
+    y = audioread(path, 16000)                       # resampling path (parity unpinned: reference uses librosa/soxr)
+    assert abs(len(y) - 2 * len(x)) <= 1 and np.isfinite(y).all()
+
+
+def test_wav_write_rule_is_pinned_by_a_reference_output(golden_dir, tmp_path):
+    """A peak-normalised waveform the reference wrote (outputs/clean/output) holds -32768 (x = -1.0):
+    scale 32768 with clipping.  Reading it and writing it back must reproduce the sample bytes."""
+    import wave
+    from speech_separation_amd.wavio import read_wav, write_wav
+    src = os.path.join(golden_dir, "ref_output_peaknorm_8k.wav")
+    x, fs = read_wav(src)
+    assert x.min() == -1.0                           # the peak sample of this file is -32768
+    out = str(tmp_path / "again.wav")
+    write_wav(out, x, fs)
+    a, b = wave.open(src, "rb"), wave.open(out, "rb")
+    assert (b.getnchannels(), b.getsampwidth(), b.getframerate(), b.getnframes()) == (1, 2, 8000, a.getnframes())
+    assert a.readframes(a.getnframes()) == b.readframes(b.getnframes())
+    a.close(); b.close()
+    write_wav(out, np.array([1.0, -1.0, 0.5, 2.0, -2.0, 1.5 / 32768.0, 2.5 / 32768.0]), 8000)
+    y, _ = read_wav(out)
+    assert np.array_equal(y * 32768.0, [32767, -32768, 16384, 32767, -32768, 2, 2])   # clip; round half to even
+
+
+def test_find_inputs(tmp_path):
+    from speech_separation_amd.wavio import find_inputs
+    d = tmp_path / "in"
+    (d / "sub").mkdir(parents=True)
+    for n in ("b.wav", "a.wav", "sub/c.WAV", "x.txt"):
+        (d / n).write_bytes(b"")
+    got = find_inputs(str(d))
+    assert [os.path.relpath(p, d) for p in got] == ["a.wav", "b.wav", "sub/c.WAV"]
+    assert find_inputs(str(d / "a.wav")) == [str(d / "a.wav")]
+    lst = tmp_path / "list.scp"
+    lst.write_text(f"{d / 'a.wav'} extra\n\n{d / 'b.wav'}\n")
+    assert find_inputs(str(lst)) == [str(d / "a.wav"), str(d / "b.wav")]
