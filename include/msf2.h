@@ -221,6 +221,21 @@ int msf2_decoder(const float* sep, const float* dec_w, float* est, int B, int S,
                  void* ws, size_t ws_bytes, void* stream);
 size_t msf2_decoder_ws_bytes(int B, int S);
 
+/*
+ * Permutation-invariant SI-SNR of two separated sources against their references, per utterance
+ * (reference: losses/loss.py:653-723 cal_si_snr -- zero-mean both, project, 10 log10 with EPS = 1e-8 in
+ * the same three places -- and the two-source case of PitWrapper, losses/loss.py:24-178, as used by
+ * get_si_snr_with_pitwrapper :632-650).  The statistic stays on the device: a sweep gathers B floats per
+ * batch instead of the waveforms.
+ *   est, src : [2][B][T] fp32
+ *   si_snr   : [B][2 (source)][2 (estimate)] dB, may be null
+ *   best     : [B] mean SI-SNR (dB) of the better speaker assignment, may be null
+ *   perm     : [B] 0 = identity assignment, 1 = swapped, may be null
+ */
+int msf2_pit_si_snr(const float* est, const float* src, float* si_snr, float* best, int* perm, int B, int T,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t msf2_pit_si_snr_ws_bytes(int B, int T);
+
 #ifdef __cplusplus
 }
 #endif

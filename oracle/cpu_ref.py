@@ -257,3 +257,33 @@ def decode_one_audio(model_fn, inputs, sampling_rate=8000, decode_window=1,
         out = [o[s][0, :].cpu().numpy() for s in range(num_spks)]
     m = max(float(np.max(np.abs(a))) for a in out)
     return [a / m for a in out]
+
+
+# ---------------------------------------------------------------------------
+# SI-SNR with 2-source permutation invariance (reference: losses/loss.py:653-723 cal_si_snr, full-length mask;
+# PitWrapper :24-178 for two sources = the better of the two assignments by mean loss)
+# ---------------------------------------------------------------------------
+def cal_si_snr(source, estimate):
+    """source, estimate: [T, B, C] -> SI-SNR in dB [B, C] (the reference returns its negative, as a loss)."""
+    EPS = 1e-8
+    n = float(source.shape[0])
+    zs = source - source.sum(0, keepdim=True) / n
+    ze = estimate - estimate.sum(0, keepdim=True) / n
+    dot = (ze * zs).sum(0, keepdim=True)
+    energy = (zs ** 2).sum(0, keepdim=True) + EPS
+    proj = dot * zs / energy
+    noise = ze - proj
+    ratio = (proj ** 2).sum(0) / ((noise ** 2).sum(0) + EPS)
+    return 10 * torch.log10(ratio + EPS)
+
+
+def pit_si_snr(est, src):
+    """est, src: [2, B, T] -> (si_snr [B, 2 (source), 2 (estimate)], best [B], perm [B])."""
+    B = est.shape[1]
+    si = torch.empty((B, 2, 2), dtype=est.dtype)
+    for s_ in range(2):
+        for e_ in range(2):
+            si[:, s_, e_] = cal_si_snr(src[s_].t().unsqueeze(-1), est[e_].t().unsqueeze(-1))[:, 0]
+    keep = 0.5 * (si[:, 0, 0] + si[:, 1, 1])
+    swap = 0.5 * (si[:, 0, 1] + si[:, 1, 0])
+    return si, torch.maximum(keep, swap), (swap > keep).to(torch.int32)

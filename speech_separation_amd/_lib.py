@@ -71,6 +71,8 @@ SYMBOLS = {
     "msf2_gated_tcn": (_i, [_vp, C.POINTER(LayerWeights), _i, _i, _i, _i, _vp, _sz, _vp]),
     "msf2_tcn_pointwise": (_i, [_vp, _vp, _vp, C.POINTER(TcnWeights), _vp, _i, _i, _i, _i, _vp]),
     "msf2_decoder_ws_bytes": (_sz, [_i, _i]),
+    "msf2_pit_si_snr_ws_bytes": (_sz, [_i, _i]),
+    "msf2_pit_si_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "msf2_decoder": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

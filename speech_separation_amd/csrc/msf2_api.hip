@@ -623,6 +623,22 @@ int msf2_diag_read2(unsigned long long* host, size_t n) {
 }
 #endif
 
+size_t msf2_pit_si_snr_ws_bytes(int B, int T) {
+    if (B < 1 || T < 1) return 0;
+    return align_up((size_t)B * cdiv(T, PIT_CHUNK) * 12 * sizeof(double));
+}
+
+int msf2_pit_si_snr(const float* est, const float* src, float* si_snr, float* best, int* perm, int B, int T, void* ws,
+                    size_t ws_bytes, void* stream) {
+    if (!est || !src || (!si_snr && !best && !perm) || B < 1 || T < 2 || !ws) return MSF2_ERR_ARG;
+    if (ws_bytes < msf2_pit_si_snr_ws_bytes(B, T)) return MSF2_ERR_WORKSPACE;
+    const int nblk = cdiv(T, PIT_CHUNK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pit_moments_kernel, dim3(nblk, B), dim3(256), 0, st, est, src, (double*)ws, B, T);
+    hipLaunchKernelGGL(pit_finalize_kernel, dim3(B), dim3(64), 0, st, (const double*)ws, nblk, T, si_snr, best, perm);
+    return check_launch();
+}
+
 size_t msf2_decoder_ws_bytes(int B, int S) { return align_up((size_t)B * S * 16 * sizeof(float)); }
 
 int msf2_decoder(const float* sep, const float* dec_w, float* est, int B, int S, int C, int T, void* ws, size_t ws_bytes,

@@ -543,4 +543,77 @@ __global__ void decoder_ola_kernel(const float* __restrict__ fv, float* __restri
     est[i] = v;
 }
 
+// ---- permutation-invariant SI-SNR of two separated sources -----------------
+// est, src: [2][B][T].  One pass over the four waveforms: every block accumulates, in double precision, the
+// 12 raw moments (sum and sum of squares of each waveform, the 4 cross products) of its chunk of one
+// utterance; pit_finalize turns the moments into the four zero-mean SI-SNR values and picks the better of the
+// two speaker assignments.  grid (nblk, B), block 256; part: [B][nblk][12] doubles.
+constexpr int PIT_CHUNK = 8192;       // samples per block
+__device__ __forceinline__ double block_sum_256_f64(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void pit_moments_kernel(const float* __restrict__ est, const float* __restrict__ src,
+                                                          double* __restrict__ part, int B, int T) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const long t0 = (long)blockIdx.x * PIT_CHUNK, t1 = min(t0 + PIT_CHUNK, (long)T);
+    const float* e0 = est + (long)b * T;
+    const float* e1 = est + ((long)B + b) * T;
+    const float* s0 = src + (long)b * T;
+    const float* s1 = src + ((long)B + b) * T;
+    double m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = 0.0;
+    for (long t = t0 + threadIdx.x; t < t1; t += 256) {
+        const double a0 = e0[t], a1 = e1[t], c0 = s0[t], c1 = s1[t];
+        m[0] += a0; m[1] += a1; m[2] += c0; m[3] += c1;
+        m[4] += a0 * a0; m[5] += a1 * a1; m[6] += c0 * c0; m[7] += c1 * c1;
+        m[8] += a0 * c0; m[9] += a0 * c1; m[10] += a1 * c0; m[11] += a1 * c1;
+    }
+    double* out = part + ((long)b * gridDim.x + blockIdx.x) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const double v = block_sum_256_f64(m[i], red);
+        if (threadIdx.x == 0) out[i] = v;
+    }
+}
+// grid B, block 64.  si_snr: [B][2 (source)][2 (estimate)] in dB; best: [B] mean SI-SNR of the better assignment;
+// perm: [B] 0 = (est0->src0, est1->src1), 1 = swapped.
+__global__ __launch_bounds__(64) void pit_finalize_kernel(const double* __restrict__ part, int nblk, int T,
+                                                          float* __restrict__ si_snr, float* __restrict__ best,
+                                                          int* __restrict__ perm) {
+    const int b = blockIdx.x;
+    double m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        double v = 0.0;
+        for (int k = threadIdx.x; k < nblk; k += 64) v += part[((long)b * nblk + k) * 12 + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        m[i] = v;
+    }
+    if (threadIdx.x != 0) return;
+    const double n = (double)T, EPS = 1e-8;
+    double val[2][2];
+    for (int si = 0; si < 2; ++si)
+        for (int ei = 0; ei < 2; ++ei) {
+            const double se = m[6 + si] - m[2 + si] * m[2 + si] / n;                 // |s~|^2
+            const double ee = m[4 + ei] - m[ei] * m[ei] / n;                         // |e~|^2
+            const double dot = m[8 + 2 * ei + si] - m[ei] * m[2 + si] / n;           // <e~, s~>
+            const double k = dot / (se + EPS);
+            const double proj = k * k * se;
+            const double noise = fmax(ee - 2.0 * k * dot + proj, 0.0);
+            val[si][ei] = 10.0 * log10(proj / (noise + EPS) + EPS);
+            if (si_snr) si_snr[(b * 2 + si) * 2 + ei] = (float)val[si][ei];
+        }
+    const double keep = 0.5 * (val[0][0] + val[1][1]), swap = 0.5 * (val[0][1] + val[1][0]);
+    if (best) best[b] = (float)fmax(keep, swap);
+    if (perm) perm[b] = swap > keep ? 1 : 0;
+}
+
 }  // namespace msf2

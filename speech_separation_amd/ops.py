@@ -117,3 +117,19 @@ def tcn_pointwise(h, t, bstat, tcn_weights, precision=_lib.PREC_FP32):
     _lib.check(lib.msf2_tcn_pointwise(h.data_ptr(), t.data_ptr(), bstat.data_ptr(), tcn_weights, out.data_ptr(),
                                       B, S, C, precision, _stream(h)), "msf2_tcn_pointwise")
     return out
+
+
+def pit_si_snr(est, src):
+    """est, src: [2, B, T] fp32 on the GPU -> (si_snr [B, 2 (source), 2 (estimate)] dB, best [B] dB,
+    perm [B] int32: 0 identity, 1 swapped).  Reference: losses/loss.py:653-723 with the 2-source PitWrapper."""
+    lib = _lib.load()
+    _chk(est, src)
+    assert est.shape == src.shape and est.shape[0] == 2 and est.dim() == 3
+    _, B, T = est.shape
+    si = torch.empty((B, 2, 2), dtype=torch.float32, device=est.device)
+    best = torch.empty((B,), dtype=torch.float32, device=est.device)
+    perm = torch.empty((B,), dtype=torch.int32, device=est.device)
+    ws = _ws(lib.msf2_pit_si_snr_ws_bytes(B, T), est.device)
+    _lib.check(lib.msf2_pit_si_snr(est.data_ptr(), src.data_ptr(), si.data_ptr(), best.data_ptr(), perm.data_ptr(), B, T,
+                                   ws.data_ptr(), ws.numel(), _stream(est)), "msf2_pit_si_snr")
+    return si, best, perm

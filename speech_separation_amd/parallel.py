@@ -64,9 +64,20 @@ def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device
     plan = assign_items(make_work_items(lengths, max_batch, max_samples), world)
     mine = plan[rank]
     local = {}
+    on_gpu = torch.device(device).type == "cuda"
+    acc = np.zeros(3)
     for n, idx in mine:
         x = torch.from_numpy(np.stack([utterances[i] for i in idx], 0).astype(np.float32)).to(device)
         out = model_fn(x)
+        if references is not None and on_gpu:
+            # the statistic is reduced where the waveforms are (msf2_pit_si_snr): B floats leave the device
+            from . import ops
+            est = torch.stack(list(out), 0).contiguous()                       # [spk, B, T]
+            src = torch.from_numpy(np.stack([np.stack([references[i][k] for i in idx], 0) for k in range(2)], 0)
+                                   .astype(np.float32)).to(device)
+            _, best, _ = ops.pit_si_snr(est, src)
+            v = best.double().cpu().numpy()
+            acc += (v.sum(), (v * v).sum(), float(len(idx)))
         out = torch.stack(list(out), 1)                    # [B, spk, T]
         for j, i in enumerate(idx):
             local[i] = out[j]
@@ -74,11 +85,11 @@ def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device
 
     stats = None
     if references is not None:
-        acc = np.zeros(3)
-        for i, o in local.items():
-            e = o.detach().cpu().numpy()
-            v = permute_si_sdr(e[0], e[1], references[i][0], references[i][1])
-            acc += (v, v * v, 1.0)
+        if not on_gpu:
+            for i, o in local.items():
+                e = o.detach().cpu().numpy()
+                v = permute_si_sdr(e[0], e[1], references[i][0], references[i][1])
+                acc += (v, v * v, 1.0)
         t = torch.tensor(acc, dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)

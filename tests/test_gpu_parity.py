@@ -397,3 +397,44 @@ def test_file_to_file_driver(golden_dir, tmp_path):
         assert fs == 8000 and x.shape == (24360,)
         peaks.append(np.abs(x).max())
     assert 0.2 < max(peaks) <= 1.0                  # joint peak normalisation over the padded length (reference: utils/decode.py:78-83)
+
+
+def test_pit_si_snr(golden_dir):
+    """Device PIT SI-SNR against the oracle restatement of the reference's cal_si_snr (fp64) and against the
+    values the reference itself produced for the fixture (same-index pairs)."""
+    z = np.load(os.path.join(golden_dir, "si_snr.npz"))
+    src = torch.from_numpy(z["src"]).permute(2, 1, 0).contiguous()        # [T, B, C] -> [C, B, T]
+    est = torch.from_numpy(z["est"]).permute(2, 1, 0).contiguous()
+    si, best, perm = ops.pit_si_snr(est.to(DEV), src.to(DEV))
+    ref_si, ref_best, ref_perm = cpu_ref.pit_si_snr(est.double(), src.double())
+    assert float((si.cpu().double() - ref_si).abs().max()) <= 1e-3
+    assert float((best.cpu().double() - ref_best).abs().max()) <= 1e-3
+    assert torch.equal(perm.cpu(), ref_perm)
+    for b in range(3):
+        for c in range(2):
+            assert abs(float(si[b, c, c]) - float(z["si_snr"][b, c])) <= 1e-3
+    # long, odd length, many blocks, a DC offset and swapped speakers
+    g = torch.Generator().manual_seed(5)
+    B, T = 5, 100003
+    s = torch.randn(2, B, T, generator=g) + 0.3
+    e = s.flip(0) * 0.8 + 0.1 * torch.randn(2, B, T, generator=g)
+    e[:, 3] = s[:, 3] + 0.05 * torch.randn(2, T, generator=g)
+    si, best, perm = ops.pit_si_snr(e.to(DEV), s.to(DEV))
+    ref_si, ref_best, ref_perm = cpu_ref.pit_si_snr(e.double(), s.double())
+    assert float((si.cpu().double() - ref_si).abs().max()) <= 1e-3
+    assert torch.equal(perm.cpu(), ref_perm) and perm.cpu().tolist() == [1, 1, 1, 0, 1]
+
+
+def test_sweep_statistic_on_device(models):
+    """separate_sharded on the GPU reduces SI-SDR with the device kernel: same statistic as the host formula
+    (reference: utils/si_sdr_numpy.py:27-41) up to the EPS terms of cal_si_snr."""
+    from speech_separation_amd.parallel import separate_sharded
+    from speech_separation_amd.synth import permute_si_sdr, synth_mixture
+    m = models("tiny")
+    data = [synth_mixture(n, i) for i, n in enumerate((8000, 8000, 12000))]
+    utts = [d[0] for d in data]
+    refs = [(d[1], d[2]) for d in data]
+    outs, stats = separate_sharded(lambda x: m(x), utts, device=DEV, references=refs, max_batch=4)
+    host = [permute_si_sdr(o[0], o[1], r[0], r[1]) for o, r in zip(outs, refs)]
+    assert stats[2] == 3.0
+    assert abs(stats[0] - sum(host)) <= 3e-3

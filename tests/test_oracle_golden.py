@@ -122,3 +122,15 @@ def test_si_sdr_known_answers(golden_dir):
     for b in range(src.shape[1]):
         for c in range(src.shape[2]):
             assert si_sdr(est[:, b, c], src[:, b, c]) == pytest.approx(ref[b, c], abs=1e-3)
+
+
+def test_cal_si_snr_matches_reference_values(golden_dir):
+    """oracle cal_si_snr against values computed by the reference's own cal_si_snr (losses/loss.py:653-723)."""
+    z = np.load(os.path.join(golden_dir, "si_snr.npz"))
+    got = cpu_ref.cal_si_snr(torch.from_numpy(z["src"]).double(), torch.from_numpy(z["est"]).double()).numpy()
+    assert np.abs(got - z["si_snr"]).max() <= 1e-3
+    # the docstring example holds exact matches (> 130 dB: the "noise" is rounding): evaluate it in fp32 as the reference did
+    xs = torch.tensor([[1, 0], [123, 45], [34, 5], [2312, 421]], dtype=torch.float32)
+    xh = xs[:, (1, 0)]
+    doc = cpu_ref.cal_si_snr(xs.unsqueeze(-1).repeat(1, 1, 2), xh.unsqueeze(1).repeat(1, 2, 1)).numpy()
+    assert np.abs(doc - z["doc_example"]).max() <= 2e-3
