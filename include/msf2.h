@@ -134,7 +134,7 @@ int msf2_last_hip_error(void);
 int msf2_version(void);
 /* sizeof() of the ABI structs as this library was compiled, for bindings to
  * verify their mirror: 0 msf2_config, 1 msf2_tcn_weights, 2 msf2_layer_weights,
- * 3 msf2_weights, 4 msf2_taps; -1 for any other index. */
+ * 3 msf2_weights, 4 msf2_taps, 5 msf2_fsmn_weights; -1 for any other index. */
 int msf2_sizeof(int which);
 
 /* Measurement aid with no counterpart in the reference (the reference times whole
@@ -220,6 +220,45 @@ int msf2_tcn_pointwise(const float* h, const float* t, const float* bstat, const
 int msf2_decoder(const float* sep, const float* dec_w, float* est, int B, int S, int C, int T,
                  void* ws, size_t ws_bytes, void* stream);
 size_t msf2_decoder_ws_bytes(int B, int S);
+
+/*
+ * FSMN-family recurrent block, replaces Gated_FSMN_Block_Dilated.forward
+ * (reference: models/mossformer2/mossformer2_block.py:434-463 with Gated_FSMN_dilated :361-393, FFConvM with
+ * LayerNorm :79-100, UniDeepFsmn_dilated / DilatedDenseNet models/mossformer2/fsmn.py:62-114, CLayerNorm
+ * models/mossformer2/layer_norm.py:14-35).  The block is not reachable from MossFormer2_SS in the
+ * reference revision this library follows (its layers use GatedTCNBlock), so it is a stand-alone
+ * operator: fp32, x and y [B, S, dim], inner = the block's inner_channels (256 in the reference).
+ * Weights as packed by speech_separation_amd.packing.pack_fsmn_block:
+ */
+typedef struct msf2_fsmn_weights {
+    const float* w1;      /* [inner][dim]  conv1.0.weight                      */
+    const float* b1;      /* [inner]                                            */
+    float prelu1;         /* conv1.1.weight (one slope)                         */
+    const float* ln1_g;   /* [inner] norm1                                      */
+    const float* ln1_b;
+    const float* w_uv;    /* [2 inner][inner] to_u | to_v Linear, LayerNorm gain folded in */
+    const float* c1_uv;   /* [2 inner] W beta + bias                            */
+    const float* c2_uv;   /* [2 inner] row sums of the folded weights           */
+    const float* dw_uv;   /* [17][2 inner] ConvModule filters, tap major        */
+    const float* w_lin;   /* [inner][inner] fsmn.linear                         */
+    const float* b_lin;
+    const float* w_proj;  /* [inner][inner] fsmn.project (no bias)              */
+    const float* w_c1;    /* [39][inner]    fsmn.conv.conv1, tap major          */
+    const float* in1_g;   /* [inner] fsmn.conv.norm1 / prelu1                   */
+    const float* in1_b;
+    const float* pr1;
+    const float* w_c2;    /* [39][2][inner] fsmn.conv.conv2, tap major, input-of-group major */
+    const float* in2_g;
+    const float* in2_b;
+    const float* pr2;
+    const float* ln2_g;   /* [inner] norm2                                      */
+    const float* ln2_b;
+    const float* w2;      /* [dim][inner]  conv2.weight                         */
+    const float* b2;      /* [dim]                                              */
+} msf2_fsmn_weights;
+int msf2_gated_fsmn(const float* x, const msf2_fsmn_weights* w, float* y, int B, int S, int dim, int inner,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t msf2_gated_fsmn_ws_bytes(int B, int S, int dim, int inner);
 
 /*
  * Permutation-invariant SI-SNR of two separated sources against their references, per utterance

@@ -287,3 +287,53 @@ def pit_si_snr(est, src):
     keep = 0.5 * (si[:, 0, 0] + si[:, 1, 1])
     swap = 0.5 * (si[:, 0, 1] + si[:, 1, 0])
     return si, torch.maximum(keep, swap), (swap > keep).to(torch.int32)
+
+
+# ---------------------------------------------------------------------------
+# FSMN-family recurrent block (dormant in the reference's live model, kept behind a constructor switch):
+# Gated_FSMN_Block_Dilated (reference: mossformer2_block.py:434-463), Gated_FSMN_dilated (:361-393),
+# FFConvM with LayerNorm (:79-100), UniDeepFsmn_dilated and DilatedDenseNet (fsmn.py:62-114),
+# CLayerNorm (layer_norm.py:14-35).  W: state_dict of the block; x: [B, S, dim].
+# ---------------------------------------------------------------------------
+def _ffconvm_ln(x, W, p):
+    n = layer_norm(x, W[f"{p}.mdl.0.weight"], W[f"{p}.mdl.0.bias"], 1e-5)
+    h = F.silu(n @ W[f"{p}.mdl.1.weight"].t() + W[f"{p}.mdl.1.bias"])
+    return h + dwconv_time(h, W[f"{p}.mdl.3.sequential.1.conv.weight"])
+
+
+def _instance_norm_prelu(t, gain, bias, slope, eps=1e-5):
+    """InstanceNorm2d(affine) over time per (utterance, channel), then per-channel PReLU.  t: [B, S, C]."""
+    mu = t.mean(dim=1, keepdim=True)
+    var = ((t - mu) ** 2).mean(dim=1, keepdim=True)
+    y = (t - mu) / torch.sqrt(var + eps) * gain + bias
+    return torch.where(y >= 0, y, y * slope)
+
+
+def dilated_dense_net(p1, W, p, lorder=20):
+    """depth 2.  Stage 1: depthwise 39-tap conv (dilation 1).  Stage 2: 39-tap conv with dilation 2 over
+    cat[out1, p1] in 256 groups of 2 input channels: group g reads channels 2g, 2g+1 of the concatenation."""
+    C = p1.shape[-1]
+    k = 2 * lorder - 1
+    w1 = W[f"{p}.conv1.weight"][:, :, :, 0]                      # [C, 1, k]
+    t1 = F.conv1d(p1.transpose(1, 2), w1, None, padding=(k - 1) // 2, groups=C).transpose(1, 2)
+    out1 = _instance_norm_prelu(t1, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], W[f"{p}.prelu1.weight"])
+    skip = torch.cat((out1, p1), dim=-1)                          # [B, S, 2C]
+    w2 = W[f"{p}.conv2.weight"][:, :, :, 0]                      # [C, 2, k]
+    t2 = F.conv1d(skip.transpose(1, 2), w2, None, padding=(k - 1), dilation=2, groups=C).transpose(1, 2)
+    return _instance_norm_prelu(t2, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], W[f"{p}.prelu2.weight"])
+
+
+def gated_fsmn_block_dilated(x, W, p=""):
+    pre = (p + ".") if p else ""
+    c1 = x @ W[f"{pre}conv1.0.weight"][:, :, 0].t() + W[f"{pre}conv1.0.bias"]
+    c1 = torch.where(c1 >= 0, c1, c1 * W[f"{pre}conv1.1.weight"])
+    n1 = layer_norm(c1, W[f"{pre}norm1.weight"], W[f"{pre}norm1.bias"], 1e-5)
+    g = f"{pre}gated_fsmn"
+    xu = _ffconvm_ln(n1, W, f"{g}.to_u")
+    xv = _ffconvm_ln(n1, W, f"{g}.to_v")
+    f1 = torch.relu(xu @ W[f"{g}.fsmn.linear.weight"].t() + W[f"{g}.fsmn.linear.bias"])
+    p1 = f1 @ W[f"{g}.fsmn.project.weight"].t()
+    xu = xu + dilated_dense_net(p1, W, f"{g}.fsmn.conv")
+    seq = xv * xu + n1
+    n2 = layer_norm(seq, W[f"{pre}norm2.weight"], W[f"{pre}norm2.bias"], 1e-5)
+    return n2 @ W[f"{pre}conv2.weight"][:, :, 0].t() + W[f"{pre}conv2.bias"] + x

@@ -114,14 +114,49 @@ def run_with_taps(model, x):
     return out, {k: v.contiguous().numpy() for k, v in taps.items()}
 
 
+def write_fsmn_fixture(out_dir):
+    # ---- FSMN-family block (dormant in the live model; mossformer2_block.py:434-463) ----
+    from models.mossformer2.mossformer2_block import Gated_FSMN_Block_Dilated
+    blk = Gated_FSMN_Block_Dilated(64, inner_channels=64).eval()
+    r = np.random.default_rng(11)
+    fs = {}
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():
+            shape = tuple(v.shape)
+            if ("norm" in k or ".mdl.0." in k) and k.endswith("weight"):
+                w = 1.0 + 0.1 * r.standard_normal(shape)
+            elif "prelu" in k or k == "conv1.1.weight":
+                w = 0.25 + 0.05 * r.standard_normal(shape)
+            elif k.endswith("bias"):
+                w = 0.05 * r.standard_normal(shape)
+            else:
+                fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+                w = r.uniform(-1, 1, shape) / np.sqrt(fan_in)
+            v.copy_(torch.from_numpy(w.astype(np.float32)))
+            fs["w:" + k] = v.numpy().copy()
+        for name, (B, S) in (("a", (2, 301)), ("b", (1, 1000))):
+            x = torch.from_numpy(r.standard_normal((B, S, 64)).astype(np.float32))
+            fs["in_" + name] = x.numpy()
+            fs["out_" + name] = blk(x).numpy()
+    f = os.path.join(out_dir, "fsmn_block.npz")
+    np.savez_compressed(f, **fs)
+    print("wrote", f, {k: v.shape for k, v in fs.items() if not k.startswith("w:")})
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--full", action="store_true", help="also run the 24-layer 512-dim model (minutes)")
+    ap.add_argument("--only-fsmn", action="store_true", help="write only the FSMN-block fixture")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     install_shims()
     torch.set_num_threads(8)
+    if a.only_fsmn:
+        sys.path.insert(0, REF)
+        write_fsmn_fixture(a.out)
+        return
     from speech_separation_amd.config import TINY, SMALL, FULL_8K
     from speech_separation_amd.synth import synth_batch
 
@@ -192,6 +227,8 @@ def main():
     f = os.path.join(a.out, "decode_tiny.npz")
     np.savez_compressed(f, **dec)
     print("wrote", f, {k: v.shape for k, v in dec.items()})
+
+    write_fsmn_fixture(a.out)
 
     # ---- SI-SNR known answers (losses/loss.py) ------------------------------
     from losses.loss import cal_si_snr  # reference; imports only torch/numpy

@@ -44,6 +44,15 @@ class Weights(C.Structure):
                 ("dec_w", C.c_void_p), ("layers", C.POINTER(LayerWeights))]
 
 
+class FsmnWeights(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("prelu1", C.c_float), ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p),
+                ("w_uv", C.c_void_p), ("c1_uv", C.c_void_p), ("c2_uv", C.c_void_p), ("dw_uv", C.c_void_p),
+                ("w_lin", C.c_void_p), ("b_lin", C.c_void_p), ("w_proj", C.c_void_p), ("w_c1", C.c_void_p),
+                ("in1_g", C.c_void_p), ("in1_b", C.c_void_p), ("pr1", C.c_void_p), ("w_c2", C.c_void_p),
+                ("in2_g", C.c_void_p), ("in2_b", C.c_void_p), ("pr2", C.c_void_p), ("ln2_g", C.c_void_p),
+                ("ln2_b", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p)]
+
+
 class Taps(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("enc", "x0", "flash0", "tcn0", "mdl", "mask0", "mask1")]
 
@@ -71,6 +80,8 @@ SYMBOLS = {
     "msf2_gated_tcn": (_i, [_vp, C.POINTER(LayerWeights), _i, _i, _i, _i, _vp, _sz, _vp]),
     "msf2_tcn_pointwise": (_i, [_vp, _vp, _vp, C.POINTER(TcnWeights), _vp, _i, _i, _i, _i, _vp]),
     "msf2_decoder_ws_bytes": (_sz, [_i, _i]),
+    "msf2_gated_fsmn_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "msf2_gated_fsmn": (_i, [_vp, C.POINTER(FsmnWeights), _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "msf2_pit_si_snr_ws_bytes": (_sz, [_i, _i]),
     "msf2_pit_si_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "msf2_decoder": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -104,7 +115,7 @@ def load():
             raise Msf2Error(f"libmsf2.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    for which, st in enumerate((Config, TcnWeights, LayerWeights, Weights, Taps)):
+    for which, st in enumerate((Config, TcnWeights, LayerWeights, Weights, Taps, FsmnWeights)):
         if lib.msf2_sizeof(which) != C.sizeof(st):
             raise Msf2Error(f"ABI mismatch: {st.__name__} is {C.sizeof(st)} bytes here, "
                             f"{lib.msf2_sizeof(which)} in libmsf2.so")

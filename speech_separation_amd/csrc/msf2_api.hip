@@ -385,6 +385,7 @@ int msf2_sizeof(int which) {
         case 2: return (int)sizeof(msf2_layer_weights);
         case 3: return (int)sizeof(msf2_weights);
         case 4: return (int)sizeof(msf2_taps);
+        case 5: return (int)sizeof(msf2_fsmn_weights);
         default: return -1;
     }
 }
@@ -622,6 +623,83 @@ int msf2_diag_read2(unsigned long long* host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(msf2::g_stamp2), n * sizeof(unsigned long long));
 }
 #endif
+
+// ---- FSMN-family block -------------------------------------------------------
+struct FsmnWs {
+    float *c1, *n1, *uv_pre, *uv, *f1, *p1, *t1, *o1, *t2, *seq, *n2, *rowstat, *part, *stats;
+    int ntile;
+};
+static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
+    FsmnWs w;
+    const long M = (long)B * S;
+    w.ntile = cdiv(S, FS_TS);
+    w.c1 = ar.take<float>(M * inner);   w.n1 = ar.take<float>(M * inner);
+    w.uv_pre = ar.take<float>(M * 2 * inner);  w.uv = ar.take<float>(M * 2 * inner);
+    w.f1 = ar.take<float>(M * inner);   w.p1 = ar.take<float>(M * inner);
+    w.t1 = ar.take<float>(M * inner);   w.o1 = ar.take<float>(M * inner);
+    w.t2 = ar.take<float>(M * inner);   w.seq = ar.take<float>(M * inner);
+    w.n2 = ar.take<float>(M * inner);
+    w.rowstat = ar.take<float>(2 * M);
+    w.part = ar.take<float>(2L * B * w.ntile * inner);
+    w.stats = ar.take<float>(2L * B * inner);
+    return w;
+}
+size_t msf2_gated_fsmn_ws_bytes(int B, int S, int dim, int inner) {
+    if (B < 1 || S < 1 || dim < BK || inner < BK) return 0;
+    Arena ar(nullptr, 0);
+    fsmn_ws(ar, B, S, inner);
+    return ar.off;
+}
+int msf2_gated_fsmn(const float* x, const msf2_fsmn_weights* fw, float* y, int B, int S, int dim, int inner, void* ws,
+                    size_t ws_bytes, void* stream) {
+    if (!x || !fw || !y || !ws || B < 1 || S < 1) return MSF2_ERR_ARG;
+    if (dim < BK || (dim % BK) || dim > 1024 || inner < BK || (inner % BK) || inner > 512) return MSF2_ERR_ARG;
+    if (!fits32((long)B * S, 2 * inner > dim ? 2 * inner : dim)) return MSF2_ERR_ARG;
+    if (ws_bytes < msf2_gated_fsmn_ws_bytes(B, S, dim, inner)) return MSF2_ERR_WORKSPACE;
+    Arena ar(ws, ws_bytes);
+    const FsmnWs w = fsmn_ws(ar, B, S, inner);
+    Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
+    const long M = c.M;
+    const int C = inner;
+    {   // c1 = PReLU(x W1^T + b1)
+        ProjArgs a = proj_args(x, dim, fw->w1, dim, C, S, w.c1, C);
+        a.bias = fw->b1; a.act = 4; a.prelu = fw->prelu1;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.c1, fw->ln1_g, fw->ln1_b, w.n1, M, C, 1e-5f);
+    launch_rowstat<1>(c, w.n1, C, w.rowstat, C, 0, 1e-5f);
+    {   // [u | v] = silu(LayerNorm(n1) W^T + b), both FFConvM projections in one contraction
+        ProjArgs a = proj_args(w.n1, C, fw->w_uv, C, 2 * C, S, w.uv_pre, 2 * C);
+        a.rowstat = w.rowstat; a.c1 = fw->c1_uv; a.c2 = fw->c2_uv; a.act = 1;
+        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    }
+    launch_dwconv17(c, w.uv_pre, 2 * C, fw->dw_uv, w.uv, 2 * C, 2 * C, 0);
+    {   // f1 = relu(u Wl^T + b)
+        ProjArgs a = proj_args(w.uv, 2 * C, fw->w_lin, C, C, S, w.f1, C);
+        a.bias = fw->b_lin; a.act = 3;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    {   // p1 = f1 Wp^T
+        ProjArgs a = proj_args(w.f1, C, fw->w_proj, C, C, S, w.p1, C);
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    const dim3 cgrid(cdiv(C / 4, 64), w.ntile, B), fgrid(cdiv(C, 256), B);
+    const int egrid = cdiv(M * (C / 4), 256);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<1>, cgrid, dim3(64), 0, c.st, w.p1, (const float*)nullptr, fw->w_c1, w.t1, w.part, S, C, 1);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(in_prelu_kernel, dim3(egrid), dim3(256), 0, c.st, w.t1, w.stats, fw->in1_g, fw->in1_b, fw->pr1, w.o1, M, S, C);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<2>, cgrid, dim3(64), 0, c.st, w.o1, w.p1, fw->w_c2, w.t2, w.part, S, C, 2);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(fsmn_gate_kernel, dim3(egrid), dim3(256), 0, c.st, w.uv, w.t2, w.stats, fw->in2_g, fw->in2_b, fw->pr2, w.n1,
+                       w.seq, M, S, C);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f);
+    {   // y = x + n2 W2^T + b2
+        ProjArgs a = proj_args(w.n2, C, fw->w2, C, dim, S, y, dim);
+        a.bias = fw->b2; a.res = x; a.ldr = dim;
+        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
+    }
+    return check_launch();
+}
 
 size_t msf2_pit_si_snr_ws_bytes(int B, int T) {
     if (B < 1 || T < 1) return 0;

@@ -305,8 +305,8 @@ __device__ __forceinline__ unsigned xcd_remap() {
 // ---------------------------------------------------------------------------
 enum { A_PLAIN = 0, A_SHIFT = 1 };
 enum {
-    EPI_RS_BIAS_ACT = 0,  // act(rowscale[m] * acc + bias[n]); act 0 none, 1 SiLU, 2 sigmoid
-    EPI_NORM = 1,         // rstd * (acc - mean * c2[n]) + c1[n] (+ pe[s, n]); stats per row or per utterance
+    EPI_RS_BIAS_ACT = 0,  // act(rowscale[m] * acc + bias[n]); act 0 none, 1 SiLU, 2 sigmoid, 3 ReLU, 4 PReLU(prelu)
+    EPI_NORM = 1,         // act(rstd * (acc - mean * c2[n]) + c1[n]) (+ pe[s, n]); stats per row or per utterance; act 0 / 1
     EPI_BIAS_RES = 2,     // res[m, n] + acc + bias[n]
     EPI_RELU_MUL = 3,     // relu(acc) * res[m, n]
     EPI_TANH_SIG = 4,     // paired columns: tanh(accA + bias[n]) * sigmoid(accB + bias2[n])
@@ -326,6 +326,7 @@ struct ProjArgs {
     const float* gmul;      // EPI_TCN: optional elementwise gate multiplied onto the result, [B*S][ldo]
     const float* zeros;     // A_SHIFT: >= 128 bytes of zeros
     int act;
+    float prelu;                   // slope of act 4
     // bf16 mode: optional bf16 images of the A operands (same shape / pitch as A, A2) read by the
     // DMA kernel, and an optional bf16 copy of the output written next to the fp32 one
     const unsigned short* A16;  const unsigned short* A2_16;
@@ -512,8 +513,11 @@ struct ProjNT {
                             p[e] = r0 * x + be;
                             if (a.act == 1) p[e] = silu_f(p[e]);
                             else if (a.act == 2) p[e] = sigmoid_f(p[e]);
+                            else if (a.act == 3) p[e] = fmaxf(p[e], 0.f);
+                            else if (a.act == 4) p[e] = p[e] >= 0.f ? p[e] : p[e] * a.prelu;
                         } else if constexpr (EPI == EPI_NORM) {
                             p[e] = rs * (x - mu * f4get(c2, e)) + f4get(c1, e);
+                            if (a.act == 1) p[e] = silu_f(p[e]);
                         } else if constexpr (EPI == EPI_BIAS_RES) {
                             p[e] = x + be;
                         } else if constexpr (EPI == EPI_RELU_MUL) {

@@ -616,4 +616,162 @@ __global__ __launch_bounds__(64) void pit_finalize_kernel(const double* __restri
     if (perm) perm[b] = swap > keep ? 1 : 0;
 }
 
+// ===========================================================================
+// FSMN-family block (Gated_FSMN_Block_Dilated): the kernels beside its projections
+// ===========================================================================
+// ---- LayerNorm over the channels of each row, affine (CLayerNorm): one wave per row, C <= 1024, C % 4 == 0
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const float* __restrict__ bta, float* __restrict__ y, long M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int nq = C >> 2;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        v[i] = (q < nq) ? *reinterpret_cast<const float4*>(x + m * C + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nq) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            d2 += a * a + b * b + c * c + d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(d2) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + 4 * q), bb = *reinterpret_cast<const float4*>(bta + 4 * q);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gg.x + bb.x; o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * gg.z + bb.z; o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            *reinterpret_cast<float4*>(y + m * C + 4 * q) = o;
+        }
+    }
+}
+
+// ---- 39-tap convolution along time of the dilated dense net, 'same' zero padding, + per-(utterance, channel)
+// partial sums for the InstanceNorm that follows.
+//   NIN = 1: depthwise, t[s, c] = sum_k w[k][c] in0[s + (k - 19) dil, c]
+//   NIN = 2: 2 input channels per output channel out of the concatenation [in0 | in1] (C channels each):
+//            t[s, g] = sum_k sum_i w[k][i][g] cat[s + (k - 19) dil, 2 g + i]
+// grid (ceil(C/4 / 64), ceil(S / FS_TS), B), block 64; a thread owns 4 output channels and FS_TS frames.
+// part: [B][gridDim.y][C][2]
+constexpr int FS_TS = 8, FS_K = 39;
+template <int NIN>
+__global__ __launch_bounds__(64) void fsmn_conv39_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                         const float* __restrict__ w, float* __restrict__ t,
+                                                         float* __restrict__ part, int S, int C, int dil) {
+    const int cq = blockIdx.x * 64 + threadIdx.x;
+    if (cq >= (C >> 2)) return;
+    const int c = 4 * cq, b = blockIdx.z, s0 = blockIdx.y * FS_TS;
+    float4 acc[FS_TS];
+#pragma unroll
+    for (int o = 0; o < FS_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // input channels of this thread: NIN = 1: c..c+3 of in0; NIN = 2: 2c..2c+7 of the concatenation
+    const float* src = in0;
+    int cin = c;
+    if (NIN == 2) {
+        cin = 2 * c;
+        if (cin >= C) { src = in1; cin -= C; }
+    }
+    const float* base = src + (long)b * S * C + cin;
+    for (int k = 0; k < FS_K; ++k) {
+        float4 w0, w1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NIN == 1) w0 = *reinterpret_cast<const float4*>(w + (long)k * C + c);
+        else {
+            w0 = *reinterpret_cast<const float4*>(w + ((long)k * 2 + 0) * C + c);
+            w1 = *reinterpret_cast<const float4*>(w + ((long)k * 2 + 1) * C + c);
+        }
+#pragma unroll
+        for (int o = 0; o < FS_TS; ++o) {
+            const int s = s0 + o + (k - FS_K / 2) * dil;
+            const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
+            const float* row = base + (long)min(max(s, 0), S - 1) * C;
+            if (NIN == 1) {
+                const float4 x = *reinterpret_cast<const float4*>(row);
+                acc[o].x += w0.x * x.x * inb; acc[o].y += w0.y * x.y * inb; acc[o].z += w0.z * x.z * inb; acc[o].w += w0.w * x.w * inb;
+            } else {
+                const float4 xa = *reinterpret_cast<const float4*>(row), xb = *reinterpret_cast<const float4*>(row + 4);
+                acc[o].x += (w0.x * xa.x + w1.x * xa.y) * inb; acc[o].y += (w0.y * xa.z + w1.y * xa.w) * inb;
+                acc[o].z += (w0.z * xb.x + w1.z * xb.y) * inb; acc[o].w += (w0.w * xb.z + w1.w * xb.w) * inb;
+            }
+        }
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
+#pragma unroll
+    for (int o = 0; o < FS_TS; ++o) {
+        const int s = s0 + o;
+        if (s < S) {
+            *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = acc[o];
+            sum.x += acc[o].x; sum.y += acc[o].y; sum.z += acc[o].z; sum.w += acc[o].w;
+            sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
+        }
+    }
+    float* pp = part + (((long)b * gridDim.y + blockIdx.y) * C + c) * 2;
+    pp[0] = sum.x; pp[1] = sq.x; pp[2] = sum.y; pp[3] = sq.y; pp[4] = sum.z; pp[5] = sq.z; pp[6] = sum.w; pp[7] = sq.w;
+}
+// (mean, rstd) per (utterance, channel) from the tile partials.  grid (ceil(C / 256), B), block 256.  stats: [B][C][2]
+__global__ void in_finalize_kernel(const float* __restrict__ part, int ntile, int S, int C, float eps, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < ntile; ++i) {
+        const float* pp = part + (((long)b * ntile + i) * C + c) * 2;
+        s += (double)pp[0];
+        q += (double)pp[1];
+    }
+    const double mean = s / S, var = fmax(q / S - mean * mean, 0.0);
+    stats[((long)b * C + c) * 2] = (float)mean;
+    stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__device__ __forceinline__ float in_prelu1(float v, float mean, float rstd, float g, float bta, float slope) {
+    const float y = (v - mean) * rstd * g + bta;
+    return y >= 0.f ? y : y * slope;
+}
+// out = PReLU_c(InstanceNorm(t)) elementwise.  One thread per 4 channels of one frame.
+__global__ void in_prelu_kernel(const float* __restrict__ t, const float* __restrict__ stats, const float* __restrict__ g,
+                                const float* __restrict__ bta, const float* __restrict__ slope, float* __restrict__ out,
+                                long M, int S, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = C >> 2;
+    if (i >= M * nq) return;
+    const long m = i / nq;
+    const int c = 4 * (int)(i % nq), b = (int)(m / S);
+    const float4 v = *reinterpret_cast<const float4*>(t + m * C + c);
+    const float* st = stats + ((long)b * C + c) * 2;
+    float4 o;
+    o.x = in_prelu1(v.x, st[0], st[1], g[c], bta[c], slope[c]);
+    o.y = in_prelu1(v.y, st[2], st[3], g[c + 1], bta[c + 1], slope[c + 1]);
+    o.z = in_prelu1(v.z, st[4], st[5], g[c + 2], bta[c + 2], slope[c + 2]);
+    o.w = in_prelu1(v.w, st[6], st[7], g[c + 3], bta[c + 3], slope[c + 3]);
+    *reinterpret_cast<float4*>(out + m * C + c) = o;
+}
+// seq = v * (u + PReLU_c(InstanceNorm(t2))) + n1, with u | v the two halves of uv [M][2C]
+__global__ void fsmn_gate_kernel(const float* __restrict__ uv, const float* __restrict__ t2, const float* __restrict__ stats,
+                                 const float* __restrict__ g, const float* __restrict__ bta, const float* __restrict__ slope,
+                                 const float* __restrict__ n1, float* __restrict__ seq, long M, int S, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = C >> 2;
+    if (i >= M * nq) return;
+    const long m = i / nq;
+    const int c = 4 * (int)(i % nq), b = (int)(m / S);
+    const float4 tv = *reinterpret_cast<const float4*>(t2 + m * C + c);
+    const float4 u = *reinterpret_cast<const float4*>(uv + m * 2 * C + c), v = *reinterpret_cast<const float4*>(uv + m * 2 * C + C + c);
+    const float4 r = *reinterpret_cast<const float4*>(n1 + m * C + c);
+    const float* st = stats + ((long)b * C + c) * 2;
+    float4 o;
+    o.x = v.x * (u.x + in_prelu1(tv.x, st[0], st[1], g[c], bta[c], slope[c])) + r.x;
+    o.y = v.y * (u.y + in_prelu1(tv.y, st[2], st[3], g[c + 1], bta[c + 1], slope[c + 1])) + r.y;
+    o.z = v.z * (u.z + in_prelu1(tv.z, st[4], st[5], g[c + 2], bta[c + 2], slope[c + 2])) + r.z;
+    o.w = v.w * (u.w + in_prelu1(tv.w, st[6], st[7], g[c + 3], bta[c + 3], slope[c + 3])) + r.w;
+    *reinterpret_cast<float4*>(seq + m * C + c) = o;
+}
+
 }  // namespace msf2

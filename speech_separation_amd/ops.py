@@ -133,3 +133,19 @@ def pit_si_snr(est, src):
     _lib.check(lib.msf2_pit_si_snr(est.data_ptr(), src.data_ptr(), si.data_ptr(), best.data_ptr(), perm.data_ptr(), B, T,
                                    ws.data_ptr(), ws.numel(), _stream(est)), "msf2_pit_si_snr")
     return si, best, perm
+
+
+def gated_fsmn(x, packed):
+    """x: [B, S, dim] fp32 on the GPU; packed = packing.pack_fsmn_block(...).  Reference:
+    Gated_FSMN_Block_Dilated.forward (mossformer2_block.py:456-463)."""
+    import ctypes as C
+    lib = _lib.load()
+    w, dim, inner, _keep = packed
+    _chk(x)
+    B, S, D = x.shape
+    assert D == dim
+    y = torch.empty_like(x)
+    ws = _ws(lib.msf2_gated_fsmn_ws_bytes(B, S, dim, inner), x.device)
+    _lib.check(lib.msf2_gated_fsmn(x.data_ptr(), C.byref(w), y.data_ptr(), B, S, dim, inner, ws.data_ptr(), ws.numel(),
+                                   _stream(x)), "msf2_gated_fsmn")
+    return y

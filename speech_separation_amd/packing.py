@@ -113,3 +113,46 @@ class PackedWeights:
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._keep)
+
+
+def pack_fsmn_block(state, device, prefix=""):
+    """Device weights of one Gated_FSMN_Block_Dilated (reference: mossformer2_block.py:434-463) for
+    msf2_gated_fsmn.  state: the block's state_dict (reference key names, optionally under prefix).
+    Returns (FsmnWeights struct, dim, inner, keep-alive list)."""
+    pre = (prefix + ".") if prefix else ""
+    keep = []
+
+    def g(k):
+        return state[pre + k].detach().to(torch.float32).cpu()
+
+    def dev(t):
+        t = t.to(torch.float32).contiguous().to(device)
+        keep.append(t)
+        return t.data_ptr()
+
+    w = _lib.FsmnWeights()
+    w1 = g("conv1.0.weight")[:, :, 0]
+    inner, dim = w1.shape
+    w.w1, w.b1, w.prelu1 = dev(w1), dev(g("conv1.0.bias")), float(g("conv1.1.weight")[0])
+    w.ln1_g, w.ln1_b = dev(g("norm1.weight")), dev(g("norm1.bias"))
+    Ws, c1s, c2s, dws = [], [], [], []
+    for br in ("to_u", "to_v"):
+        q = f"gated_fsmn.{br}.mdl"
+        W, b = g(f"{q}.1.weight").double(), g(f"{q}.1.bias").double()
+        gain, beta = g(f"{q}.0.weight").double(), g(f"{q}.0.bias").double()
+        Wf = (W * gain[None, :]).float()                  # LayerNorm(x) W^T + b = rstd (x W'^T - mean c2) + c1
+        Ws.append(Wf)
+        c1s.append((W @ beta + b).float())
+        c2s.append(Wf.double().sum(1).float())
+        dws.append(g(f"{q}.3.sequential.1.conv.weight")[:, 0, :])
+    w.w_uv, w.c1_uv, w.c2_uv = dev(torch.cat(Ws, 0)), dev(torch.cat(c1s, 0)), dev(torch.cat(c2s, 0))
+    w.dw_uv = dev(torch.cat(dws, 0).t())
+    f = "gated_fsmn.fsmn"
+    w.w_lin, w.b_lin, w.w_proj = dev(g(f"{f}.linear.weight")), dev(g(f"{f}.linear.bias")), dev(g(f"{f}.project.weight"))
+    w.w_c1 = dev(g(f"{f}.conv.conv1.weight")[:, 0, :, 0].t())                  # [39][C]
+    w.in1_g, w.in1_b, w.pr1 = dev(g(f"{f}.conv.norm1.weight")), dev(g(f"{f}.conv.norm1.bias")), dev(g(f"{f}.conv.prelu1.weight"))
+    w.w_c2 = dev(g(f"{f}.conv.conv2.weight")[:, :, :, 0].permute(2, 1, 0))       # [C][2][39] -> [39][2][C]
+    w.in2_g, w.in2_b, w.pr2 = dev(g(f"{f}.conv.norm2.weight")), dev(g(f"{f}.conv.norm2.bias")), dev(g(f"{f}.conv.prelu2.weight"))
+    w.ln2_g, w.ln2_b = dev(g("norm2.weight")), dev(g("norm2.bias"))
+    w.w2, w.b2 = dev(g("conv2.weight")[:, :, 0]), dev(g("conv2.bias"))
+    return w, int(dim), int(inner), keep

@@ -438,3 +438,45 @@ def test_sweep_statistic_on_device(models):
     host = [permute_si_sdr(o[0], o[1], r[0], r[1]) for o, r in zip(outs, refs)]
     assert stats[2] == 3.0
     assert abs(stats[0] - sum(host)) <= 3e-3
+
+
+def test_gated_fsmn_block(golden_dir):
+    """FSMN-family block: against the reference module's outputs (fixture, dim 64 / inner 64) and, at the
+    reference's real size (dim 512, inner 256), against the fp64 oracle."""
+    from speech_separation_amd.packing import pack_fsmn_block
+    z = np.load(os.path.join(golden_dir, "fsmn_block.npz"))
+    W = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    pk = pack_fsmn_block(W, DEV)
+    for name in ("a", "b"):
+        got = ops.gated_fsmn(torch.from_numpy(z["in_" + name]).to(DEV), pk)
+        ref = torch.from_numpy(z["out_" + name])
+        assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 2e-5
+    g = torch.Generator().manual_seed(31)
+    dim, inner, B, S = 512, 256, 2, 1333
+    shapes = {"conv1.0.weight": (inner, dim, 1), "conv1.0.bias": (inner,), "conv1.1.weight": (1,), "norm1.weight": (inner,),
+              "norm1.bias": (inner,), "norm2.weight": (inner,), "norm2.bias": (inner,), "conv2.weight": (dim, inner, 1),
+              "conv2.bias": (dim,), "gated_fsmn.fsmn.linear.weight": (inner, inner), "gated_fsmn.fsmn.linear.bias": (inner,),
+              "gated_fsmn.fsmn.project.weight": (inner, inner), "gated_fsmn.fsmn.conv.conv1.weight": (inner, 1, 39, 1),
+              "gated_fsmn.fsmn.conv.conv2.weight": (inner, 2, 39, 1)}
+    for br in ("to_u", "to_v"):
+        shapes.update({f"gated_fsmn.{br}.mdl.0.weight": (inner,), f"gated_fsmn.{br}.mdl.0.bias": (inner,),
+                       f"gated_fsmn.{br}.mdl.1.weight": (inner, inner), f"gated_fsmn.{br}.mdl.1.bias": (inner,),
+                       f"gated_fsmn.{br}.mdl.3.sequential.1.conv.weight": (inner, 1, 17)})
+    for i in (1, 2):
+        shapes.update({f"gated_fsmn.fsmn.conv.norm{i}.weight": (inner,), f"gated_fsmn.fsmn.conv.norm{i}.bias": (inner,),
+                       f"gated_fsmn.fsmn.conv.prelu{i}.weight": (inner,)})
+    Wb = {}
+    for k, shp in shapes.items():
+        if ("norm" in k or ".mdl.0." in k) and k.endswith("weight"):
+            Wb[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif "prelu" in k or k == "conv1.1.weight":
+            Wb[k] = 0.25 + 0.05 * torch.randn(shp, generator=g)
+        elif k.endswith("bias"):
+            Wb[k] = 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
+            Wb[k] = (torch.rand(shp, generator=g) * 2 - 1) / fan ** 0.5
+    x = torch.randn(B, S, dim, generator=g)
+    ref = cpu_ref.gated_fsmn_block_dilated(x.double(), {k: v.double() for k, v in Wb.items()})
+    got = ops.gated_fsmn(x.to(DEV), pack_fsmn_block(Wb, DEV))
+    assert rel_err(got, ref) <= 2e-5

@@ -134,3 +134,12 @@ def test_cal_si_snr_matches_reference_values(golden_dir):
     xh = xs[:, (1, 0)]
     doc = cpu_ref.cal_si_snr(xs.unsqueeze(-1).repeat(1, 1, 2), xh.unsqueeze(1).repeat(1, 2, 1)).numpy()
     assert np.abs(doc - z["doc_example"]).max() <= 2e-3
+
+
+def test_fsmn_block_matches_reference(golden_dir):
+    """oracle restatement of Gated_FSMN_Block_Dilated against the reference module's own outputs."""
+    z = np.load(os.path.join(golden_dir, "fsmn_block.npz"))
+    W = {k[2:]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith("w:")}
+    for name in ("a", "b"):
+        got = cpu_ref.gated_fsmn_block_dilated(torch.from_numpy(z["in_" + name]).double(), W).numpy()
+        assert np.abs(got - z["out_" + name]).max() <= 2e-5
