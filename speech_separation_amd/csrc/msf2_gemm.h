@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
 #ifdef MSF2_DIAG_STAMP
     MSF2_STAMP(tk1)
 #endif
-    prob.template epilogue<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);   // main loop ended with a barrier: LDS is free
+    // main loop ended with a barrier: LDS is free
+    if constexpr (P::ACC_T) prob.template epilogue_rm<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);
+    else prob.template epilogue<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);
 #ifdef MSF2_DIAG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MSF2_STAMP(tk2)
@@ -424,6 +426,149 @@ struct ProjNT {
         n = min(n, a.N - 1);
         return reinterpret_cast<const unsigned short*>(w) + (long)n * a.K + kt * BK + ko;
     }
+    // Row-major form of the epilogue, used by the fp32 kernel.  Each 32x32 accumulator tile (and its partner for
+    // the two-accumulator epilogues) is moved through the wave's 4 KiB LDS tile into row-major registers FIRST
+    // (lane l: rows 8 i + (l >> 3), i = 0..3, columns 4 (l & 7) + 0..3) and all arithmetic happens there: a
+    // lane's 4 columns are the same for every row and tile of a column tile, so the per-column vectors are 3
+    // float4 per lane loaded once, instead of one dependent L2 round trip per accumulator group.  The loads of
+    // tile k+1 are issued between the arithmetic of tile k (after which its inputs are dead) and its stores,
+    // so waiting for them never drains those stores.
+    template <int TM, int TN>
+    __device__ void epilogue_rm(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage) const {
+        float mean_b = 0.f, rstd_b = 1.f;
+        if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
+        constexpr int TNE = PAIRED ? TN / 2 : TN;
+        constexpr int NT = TM * TNE;
+        constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);
+        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || EPI == EPI_TCN);
+        constexpr bool TWO = (EPI == EPI_TCN || EPI == EPI_TANH_SIG);
+        const bool has_rs = a.rowstat != nullptr;
+        const bool has_g = (EPI == EPI_TCN) && a.gmul != nullptr;
+        const unsigned ldr4 = 4u * a.ldr, ldo4 = 4u * a.ldo, m_base = (unsigned)b * a.S;
+        const int kh = lane >> 5, ar = lane & 31;      // accumulator layout
+        const int rr = lane >> 3, rc = lane & 7;       // row-major layout
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 biasv[TNE], bias2v[TNE], c1v[TNE], c2v[TNE];
+#pragma unroll
+        for (int tn = 0; tn < TNE; ++tn) {
+            const int nc = min(n0 + wc * (TN * 32) + tn * 32 + 4 * rc, a.N - 4);
+            biasv[tn] = a.bias ? ld4(a.bias + nc) : zero4;
+            bias2v[tn] = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
+            c1v[tn] = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c1 + nc) : zero4;
+            c2v[tn] = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c2 + nc) : zero4;
+        }
+        float4 rv[4], gv[4];
+        float r0[4], r1[4];
+        auto tile_rows = [&](int idx, unsigned (&mrow)[4], bool (&ok)[4]) {
+            const int srow = s0 + wr * (TM * 32) + (idx / TNE) * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = srow + 8 * i + rr;
+                ok[i] = s < a.S;
+                mrow[i] = m_base + min(s, a.S - 1);
+            }
+        };
+        auto load_tile = [&](int idx) {
+            unsigned mrow[4];
+            bool ok[4];
+            tile_rows(idx, mrow, ok);
+            const unsigned nc4 = 4u * min(n0 + wc * (TN * 32) + (idx % TNE) * 32 + 4 * rc, a.N - 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rv[i] = zero4;
+                gv[i] = one4;
+                r0[i] = 1.f;
+                r1[i] = 0.f;
+                if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
+                if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                if (EPI == EPI_NORM && a.pe) rv[i] = ldg4_off(a.pe, (mrow[i] - m_base) * (4u * a.N) + nc4);
+                if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
+                if (ROWSTAT && has_rs) {
+                    if (EPI == EPI_RS_BIAS_ACT) r0[i] = ldg_off(a.rowstat, mrow[i] * 4u);
+                    else { r1[i] = ldg_off(a.rowstat, mrow[i] * 8u); r0[i] = ldg_off(a.rowstat, mrow[i] * 8u + 4u); }
+                }
+            }
+        };
+        auto transpose = [&](const f32x16& t, float4 (&o)[4]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stage + (ar * 8 + ((2 * g + kh) ^ (ar & 7))) * 4) =
+                    make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr;
+                o[i] = *reinterpret_cast<const float4*>(stage + (row * 8 + (rc ^ (row & 7))) * 4);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        load_tile(0);
+#pragma unroll
+        for (int idx = 0; idx < NT; ++idx) {
+            const int tm = idx / TNE, tn = idx % TNE;
+            float4 x4[4], y4[4];
+            transpose(acc[0][tm][tn], x4);
+            if constexpr (EPI == EPI_TCN) transpose(acc[NSEG - 1][tm][tn], y4);
+            if constexpr (EPI == EPI_TANH_SIG) transpose(acc[0][tm][tn + TN / 2], y4);
+            float4 v[4], w2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float mu = (EPI == EPI_NORM && has_rs) ? r1[i] : mean_b, rs = (EPI == EPI_NORM && has_rs) ? r0[i] : rstd_b;
+                float ve[4], we[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = f4get(x4[i], e), y = TWO ? f4get(y4[i], e) : 0.f;
+                    const float be = f4get(biasv[tn], e), rve = f4get(rv[i], e);
+                    we[e] = 0.f;
+                    if constexpr (EPI == EPI_RS_BIAS_ACT) {
+                        ve[e] = r0[i] * x + be;
+                        if (a.act == 1) ve[e] = silu_f(ve[e]);
+                        else if (a.act == 2) ve[e] = sigmoid_f(ve[e]);
+                        else if (a.act == 3) ve[e] = fmaxf(ve[e], 0.f);
+                        else if (a.act == 4) ve[e] = ve[e] >= 0.f ? ve[e] : ve[e] * a.prelu;
+                    } else if constexpr (EPI == EPI_NORM) {
+                        ve[e] = rs * (x - mu * f4get(c2v[tn], e)) + f4get(c1v[tn], e);
+                        if (a.act == 1) ve[e] = silu_f(ve[e]);
+                        ve[e] += rve;
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        ve[e] = rve + x + be;
+                    } else if constexpr (EPI == EPI_RELU_MUL) {
+                        we[e] = fmaxf(x, 0.f);
+                        ve[e] = we[e] * rve;
+                    } else if constexpr (EPI == EPI_TANH_SIG) {
+                        ve[e] = tanhf(x + be) * sigmoid_f(y + f4get(bias2v[tn], e));
+                    } else {  // EPI_TCN
+                        ve[e] = (rve + sigmoid_f(x + be) * (rstd_b * (y - mean_b * f4get(c2v[tn], e)) + f4get(c1v[tn], e))) * f4get(gv[i], e);
+                    }
+                }
+                v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                w2[i] = make_float4(we[0], we[1], we[2], we[3]);
+            }
+            unsigned mrow[4];
+            bool ok[4];
+            tile_rows(idx, mrow, ok);
+            const int n = n0 + wc * (TN * 32) + tn * 32 + 4 * rc;
+            const bool nok = n < a.N;
+            const unsigned nc4 = 4u * min(n, a.N - 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (idx + 1 < NT) load_tile(idx + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ok[i] && nok) {
+                    const unsigned off = mrow[i] * ldo4 + nc4;
+                    if (a.out) stg4_off(a.out, off, v[i]);
+                    if (EPI == EPI_NORM && a.out2) stg4_off(a.out2, off, v[i]);
+                    if (EPI == EPI_RELU_MUL && a.out2) stg4_off(a.out2, off, w2[i]);
+                    if (a.out16) stg4_bf16_off(a.out16, off >> 1, v[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
     // Accumulators are held TRANSPOSED (ACC_T: the kernels issue the MFMA with the weight fragment
     // as its first operand): in a 32x32 tile lane l owns token row (l & 31) and, per group
     // g = 0..3, the 4 CONSECUTIVE output columns 8 g + 4 (l >> 5) + 0..3 (register 4 g + e).
