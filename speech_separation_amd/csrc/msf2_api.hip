@@ -72,9 +72,9 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         g_bad_operand = true;
         return;
     }
-    const TimedLaunch timed_(EPI == EPI_TCN ? c.st : nullptr, EPI == EPI_TCN);
+    const TimedLaunch timed_(P::NSEG == 2 ? c.st : nullptr, P::NSEG == 2);
     // (the two-product form of the DMA kernel streams the bf16 residual with the operands: it needs res16)
-    if (c.prec == MSF2_PREC_BF16 && a.A16 && (P::NSEG == 1 || (a.A2_16 && a.res16))) {
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && (EPI != EPI_TCN_G || a.gmul16)))) {
         // One workgroup walks 2 column tiles of its row tile: its ring then prefetches the second tile
         // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
         // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all
@@ -82,18 +82,15 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         int loop = 2;
         if (const char* e = getenv("MSF2_NCOL_LOOP")) loop = atoi(e) > 0 ? atoi(e) : 1;
         ProjArgs al = a;
-        if constexpr (!P::PAIRED) {
+        if constexpr (!P::PAIRED && P::NSEG == 1) {
             // 256-row tiles, one 8-wave workgroup per CU, when that still gives every CU several tiles
             typedef DmaGeom<P, 1> G;
             dim3 gb(cdiv(a.N, G::BNX), cdiv(c.S, G::BMX), c.B);
             // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 2 % slower for the
             // two-product TCN contraction and the N = 2176 projection, which keep the 128 x 128 form
-            const bool want = P::NSEG == 1 && a.N <= 1024 && getenv("MSF2_NO_BIG") == nullptr;
+            const bool want = a.N <= 1024 && getenv("MSF2_NO_BIG") == nullptr;
             if (want && (long)gb.x * gb.y * gb.z >= 1024) {
-                int lb = loop > (int)gb.x ? (int)gb.x : loop;
-                if (P::NSEG == 1) lb = 1;         // 256 columns per tile already
-                al.ncol_loop = lb;
-                gb.x = cdiv(gb.x, lb);
+                al.ncol_loop = 1;                 // 256 columns per tile already
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);
                 return;
             }
@@ -103,8 +100,10 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         al.ncol_loop = loop;
         grid.x = cdiv(grid.x, loop);
         hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 0>), grid, dim3(256), 0, c.st, al);
-    } else
+    } else {
+        if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return; }     // only the DMA kernel reads the bf16 gate
         launch_gemm<P>(c, grid, a);
+    }
 }
 
 static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N, int S, float* out, int ldo) {
@@ -192,7 +191,7 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
 // ---- gated TCN block ----------------------------------------------------------
 struct TcnWs {
     float *rowstat, *g, *h0, *h1, *t, *part, *bstat;
-    unsigned short *h16a, *h16b, *t16;     // bf16 mode: operand images of h and t
+    unsigned short *g16, *h16a, *h16b, *t16;     // bf16 mode: the gate and the operand images of h and t
     int nblk;
 };
 static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
@@ -200,12 +199,13 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     const long M = (long)B * S;
     w.nblk = cdiv(S, TCN_TS);
     w.rowstat = ar.take<float>(2 * M);
-    w.g = ar.take<float>(M * C);
     if (prec != MSF2_PREC_BF16) {
+        w.g = ar.take<float>(M * C);
         w.h0 = ar.take<float>(M * C);
         w.h1 = ar.take<float>(M * C);
     }
     if (prec == MSF2_PREC_BF16) {
+        w.g16 = ar.take<unsigned short>(M * C);
         w.h16a = ar.take<unsigned short>(M * C);
         w.h16b = ar.take<unsigned short>(M * C);
         w.t16 = ar.take<unsigned short>(M * C);
@@ -232,8 +232,8 @@ static void launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned sho
 // x16: optional bf16 image of x (read by the two projections of x, rewritten with the block's result).
 static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C) {
     {
-        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
-        a.bias = lw.b_gg; a.act = 2; a.A16 = x16;
+        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);      // the gate exists as bf16 only
+        a.bias = lw.b_gg; a.act = 2; a.A16 = x16; a.out16 = w.g16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
@@ -251,8 +251,11 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned 
         ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
         a.bstat = w.bstat; a.res16 = h16; a.ldr = C; a.out16 = hn16;
-        if (j == MSF2_TCN_DEPTH - 1) a.gmul = w.g;   // the last block hands g * h to proj_out
-        launch_proj<A_PLAIN, EPI_TCN>(c, a);
+        if (j == MSF2_TCN_DEPTH - 1) {               // the last block hands g * h to proj_out
+            a.gmul16 = w.g16;
+            launch_proj<A_PLAIN, EPI_TCN_G>(c, a);
+        } else
+            launch_proj<A_PLAIN, EPI_TCN>(c, a);
         unsigned short* t16 = h16; h16 = hn16; hn16 = t16;
     }
     {
@@ -288,8 +291,11 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
         a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
         a.bstat = w.bstat; a.res = h; a.ldr = C;
-        if (j == MSF2_TCN_DEPTH - 1) a.gmul = w.g;     // the last block hands g * h to proj_out
-        launch_proj<A_PLAIN, EPI_TCN>(c, a);
+        if (j == MSF2_TCN_DEPTH - 1) {               // the last block hands g * h to proj_out
+            a.gmul = w.g;
+            launch_proj<A_PLAIN, EPI_TCN_G>(c, a);
+        } else
+            launch_proj<A_PLAIN, EPI_TCN>(c, a);
         float* tmp = h; h = hn; hn = tmp;
     }
     // x += (g * h) Wpo^T + b
@@ -337,7 +343,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.bstat = ar.take<float>(2L * B);
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
-    w.zeros = ar.take<float>(64);
+    w.zeros = ar.take<float>(1024);      // >= K bytes: the DMA kernel's copy address of a zero row advances with k
     w.x16 = w.o16 = w.hu_pre16 = w.hu16 = nullptr;
     if (cfg.precision == MSF2_PREC_BF16) {
         w.hu_pre16 = ar.take<unsigned short>(M * NH);
@@ -437,7 +443,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     msf2_taps tp = {};
     if (taps) tp = *taps;
 
-    hipMemsetAsync(w.zeros, 0, 256, c.st);   // zero operand rows for the token shift at frame 0
+    hipMemsetAsync(w.zeros, 0, 4096, c.st);  // zero operand rows for the token shift at frame 0
     // encoder + statistics for the mask net's GroupNorm(1, C, eps 1e-8)
     hipLaunchKernelGGL(encoder_kernel, dim3(w.nblk_enc, B), dim3(256), 0, c.st, mix, wt->enc_w, w.enc, w.part, T, S, C, ENC_TS);
     launch_stats_finalize(c, w.part, w.nblk_enc, (long)S * C, 1e-8f, w.bstat);

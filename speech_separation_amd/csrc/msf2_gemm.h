@@ -274,7 +274,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
     MSF2_STAMP(tk1)
 #endif
     // main loop ended with a barrier: LDS is free
-    if constexpr (P::ACC_T) prob.template epilogue_rm<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);
+    if constexpr (P::ACC_T) {
+        typename P::template ColVecs<(P::PAIRED ? TN / 2 : TN)> cv;
+        prob.template load_colvecs<TN>(prob.n0, wc, lane, cv);
+        prob.template fold_colvecs<TN>(cv);
+        prob.template epilogue_rm<TM, TN>(acc, wr, wc, lane, smA + wave * 1024, cv);
+    }
     else prob.template epilogue<TM, TN>(acc, wr, wc, lane, smA + wave * 1024);
 #ifdef MSF2_DIAG_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,7 +317,8 @@ enum {
     EPI_BIAS_RES = 2,     // res[m, n] + acc + bias[n]
     EPI_RELU_MUL = 3,     // relu(acc) * res[m, n]
     EPI_TANH_SIG = 4,     // paired columns: tanh(accA + bias[n]) * sigmoid(accB + bias2[n])
-    EPI_TCN = 5,          // two accumulators: (res + sigmoid(acc0 + bias) * (rstd_b * (acc1 - mean_b * c2) + c1)) [* gmul]
+    EPI_TCN = 5,          // two accumulators: res + sigmoid(acc0 + bias) * (rstd_b * (acc1 - mean_b * c2) + c1)
+    EPI_TCN_G = 6,        // EPI_TCN times the elementwise gate gmul[m, n] (its own kernel: the gate costs 16 registers)
 };
 
 struct ProjArgs {
@@ -325,8 +331,9 @@ struct ProjArgs {
     const float* bstat;     // [B][2] (mean, rstd)
     const float* res;  int ldr;
     const float* pe;        // [S][N]
-    const float* gmul;      // EPI_TCN: optional elementwise gate multiplied onto the result, [B*S][ldo]
-    const float* zeros;     // A_SHIFT: >= 128 bytes of zeros
+    const float* gmul;      // EPI_TCN_G: elementwise gate multiplied onto the result, [B*S][ldo]
+    const unsigned short* gmul16;  // the same gate as bf16, read by the DMA kernel instead of gmul
+    const float* zeros;     // A_SHIFT: >= 128 bytes of zeros (>= K bytes where the DMA kernel may run: its zero-row address advances with k)
     int act;
     float prelu;                   // slope of act 4
     // bf16 mode: optional bf16 images of the A operands (same shape / pitch as A, A2) read by the
@@ -341,9 +348,10 @@ template <int AMODE, int EPI>
 struct ProjNT {
     typedef ProjArgs Args;
     static constexpr bool PAIRED = (EPI == EPI_TANH_SIG);
-    static constexpr int EPI_KIND = EPI;
+    static constexpr int EPI_KIND = EPI, A_MODE = AMODE;
     static constexpr int WR = PAIRED ? 4 : 2, WC = PAIRED ? 1 : 2;
-    static constexpr int NSEG = (EPI == EPI_TCN) ? 2 : 1;
+    static constexpr bool IS_TCN = (EPI == EPI_TCN || EPI == EPI_TCN_G);
+    static constexpr int NSEG = IS_TCN ? 2 : 1;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
     static constexpr bool B_BF16 = true;    // bf16 kernels read W as bf16
     static constexpr bool ACC_T = true;     // accumulators transposed: MFMA(weight fragment, activation fragment)
@@ -433,31 +441,72 @@ struct ProjNT {
     // float4 per lane loaded once, instead of one dependent L2 round trip per accumulator group.  The loads of
     // tile k+1 are issued between the arithmetic of tile k (after which its inputs are dead) and its stores,
     // so waiting for them never drains those stores.
-    template <int TM, int TN>
-    __device__ void epilogue_rm(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage) const {
+    // Per-column vectors of the row-major epilogue for the column tile starting at n_origin: lane l holds
+    // columns 4 (l & 7) + 0..3 of each 32-column MFMA tile.  EPI_TCN folds the utterance statistics in:
+    // c1 <- c1 - rstd_b * mean_b * c2, so the epilogue evaluates rstd_b * acc1 + c1.  Every load is issued
+    // whether or not the vector exists (a null bias reads the weights and is zeroed afterwards): callers
+    // that count outstanding memory operations rely on COLVEC_LOADS.
+    template <int TNE> struct ColVecs { float4 bias[TNE], bias2[TNE], c1[TNE], c2[TNE]; };
+    static constexpr int COLVEC_KINDS = 1 + ((EPI == EPI_NORM || IS_TCN) ? 2 : 0) + ((EPI == EPI_TANH_SIG) ? 1 : 0);
+    template <int TN>
+    __device__ void load_colvecs(int n_origin, int wc, int lane, ColVecs<(PAIRED ? TN / 2 : TN)>& cv) const {
+        constexpr int TNE = PAIRED ? TN / 2 : TN;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rc = lane & 7;
+#pragma unroll
+        for (int tn = 0; tn < TNE; ++tn) {
+            const int nc = min(n_origin + wc * (TN * 32) + tn * 32 + 4 * rc, a.N - 4);
+            cv.bias[tn] = ld4((a.bias ? a.bias : a.W) + nc);
+            cv.bias2[tn] = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
+            cv.c1[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c1 + nc) : zero4;
+            cv.c2[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c2 + nc) : zero4;
+        }
+    }
+    // second half of load_colvecs: everything that reads the loaded values (the caller may put independent
+    // memory traffic between the two)
+    template <int TN>
+    __device__ void fold_colvecs(ColVecs<(PAIRED ? TN / 2 : TN)>& cv) const {
+        constexpr int TNE = PAIRED ? TN / 2 : TN;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float mean_b = 0.f, rstd_b = 1.f;
+        if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
+#pragma unroll
+        for (int tn = 0; tn < TNE; ++tn) {
+            if (!a.bias) cv.bias[tn] = zero4;
+            if constexpr (IS_TCN) {
+                const float k = rstd_b * mean_b;
+                cv.c1[tn] = make_float4(cv.c1[tn].x - k * cv.c2[tn].x, cv.c1[tn].y - k * cv.c2[tn].y,
+                                        cv.c1[tn].z - k * cv.c2[tn].z, cv.c1[tn].w - k * cv.c2[tn].w);
+            }
+        }
+    }
+    // Row-major form of the epilogue.  RESLDS: the bf16 residual of this wave's rows sits in LDS (rtile: 64 rows
+    // x 128 columns, 256 B per row, 16-byte chunk c of row r at chunk position c ^ (r & 7)).
+    // after_first: called once, after the arithmetic of an early tile (its accumulator registers are free by then).
+    struct NoHook { __device__ void operator()() const {} };
+    template <int TM, int TN, bool RESLDS = false, class Hook = NoHook>
+    __device__ void epilogue_rm(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage,
+                                const ColVecs<(PAIRED ? TN / 2 : TN)>& cv, const char* rtile = nullptr,
+                                Hook after_first = Hook()) const {
         float mean_b = 0.f, rstd_b = 1.f;
         if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         constexpr int NT = TM * TNE;
         constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);
-        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || EPI == EPI_TCN);
-        constexpr bool TWO = (EPI == EPI_TCN || EPI == EPI_TANH_SIG);
+        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || IS_TCN);
+        constexpr bool TWO = (IS_TCN || EPI == EPI_TANH_SIG);
         const bool has_rs = a.rowstat != nullptr;
-        const bool has_g = (EPI == EPI_TCN) && a.gmul != nullptr;
+        constexpr bool has_g = (EPI == EPI_TCN_G);
         const unsigned ldr4 = 4u * a.ldr, ldo4 = 4u * a.ldo, m_base = (unsigned)b * a.S;
         const int kh = lane >> 5, ar = lane & 31;      // accumulator layout
         const int rr = lane >> 3, rc = lane & 7;       // row-major layout
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 biasv[TNE], bias2v[TNE], c1v[TNE], c2v[TNE];
-#pragma unroll
-        for (int tn = 0; tn < TNE; ++tn) {
-            const int nc = min(n0 + wc * (TN * 32) + tn * 32 + 4 * rc, a.N - 4);
-            biasv[tn] = a.bias ? ld4(a.bias + nc) : zero4;
-            bias2v[tn] = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
-            c1v[tn] = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c1 + nc) : zero4;
-            c2v[tn] = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c2 + nc) : zero4;
-        }
+        const float4 (&biasv)[TNE] = cv.bias;
+        const float4 (&bias2v)[TNE] = cv.bias2;
+        const float4 (&c1v)[TNE] = cv.c1;
+        const float4 (&c2v)[TNE] = cv.c2;
         float4 rv[4], gv[4];
+        uint2 rp[4], gp[4];         // RESLDS (bf16 DMA kernel): residual and gate stay packed bf16 until used
         float r0[4], r1[4];
         auto tile_rows = [&](int idx, unsigned (&mrow)[4], bool (&ok)[4]) {
             const int srow = s0 + wr * (TM * 32) + (idx / TNE) * 32;
@@ -479,10 +528,18 @@ struct ProjNT {
                 gv[i] = one4;
                 r0[i] = 1.f;
                 r1[i] = 0.f;
-                if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
-                if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                if constexpr (RESLDS) {
+                    const int rrow = (idx / TNE) * 32 + 8 * i + rr;                   // row inside the wave's 64-row tile
+                    const int chunk = (wc * (TN * 4) + (idx % TNE) * 4 + (rc >> 1)) ^ (rrow & 7);
+                    rp[i] = *reinterpret_cast<const uint2*>(rtile + rrow * 256 + chunk * 16 + (rc & 1) * 8);   // kept packed
+                } else {
+                    if (RES && !a.res16) rv[i] = ldg4_off(a.res, mrow[i] * ldr4 + nc4);
+                    if (RES && a.res16) rv[i] = ldg4_bf16_off(a.res16, (mrow[i] * ldr4 + nc4) >> 1);   // uniform branch
+                }
                 if (EPI == EPI_NORM && a.pe) rv[i] = ldg4_off(a.pe, (mrow[i] - m_base) * (4u * a.N) + nc4);
-                if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
+                if constexpr (has_g && RESLDS)
+                    gp[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.gmul16) + ((mrow[i] * ldo4 + nc4) >> 1));
+                else if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
                 if (ROWSTAT && has_rs) {
                     if (EPI == EPI_RS_BIAS_ACT) r0[i] = ldg_off(a.rowstat, mrow[i] * 4u);
                     else { r1[i] = ldg_off(a.rowstat, mrow[i] * 8u); r0[i] = ldg_off(a.rowstat, mrow[i] * 8u + 4u); }
@@ -510,7 +567,7 @@ struct ProjNT {
             const int tm = idx / TNE, tn = idx % TNE;
             float4 x4[4], y4[4];
             transpose(acc[0][tm][tn], x4);
-            if constexpr (EPI == EPI_TCN) transpose(acc[NSEG - 1][tm][tn], y4);
+            if constexpr (IS_TCN) transpose(acc[NSEG - 1][tm][tn], y4);
             if constexpr (EPI == EPI_TANH_SIG) transpose(acc[0][tm][tn + TN / 2], y4);
             float4 v[4], w2[4];
 #pragma unroll
@@ -520,7 +577,10 @@ struct ProjNT {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = f4get(x4[i], e), y = TWO ? f4get(y4[i], e) : 0.f;
-                    const float be = f4get(biasv[tn], e), rve = f4get(rv[i], e);
+                    const unsigned rpw = (e < 2) ? rp[i].x : rp[i].y, gpw = (e < 2) ? gp[i].x : gp[i].y;
+                    const float gve = (has_g && RESLDS) ? __builtin_bit_cast(float, (e & 1) ? (gpw & 0xffff0000u) : (gpw << 16)) : f4get(gv[i], e);
+                    const float be = f4get(biasv[tn], e);
+                    const float rve = RESLDS ? __builtin_bit_cast(float, (e & 1) ? (rpw & 0xffff0000u) : (rpw << 16)) : f4get(rv[i], e);
                     we[e] = 0.f;
                     if constexpr (EPI == EPI_RS_BIAS_ACT) {
                         ve[e] = r0[i] * x + be;
@@ -540,7 +600,7 @@ struct ProjNT {
                     } else if constexpr (EPI == EPI_TANH_SIG) {
                         ve[e] = tanhf(x + be) * sigmoid_f(y + f4get(bias2v[tn], e));
                     } else {  // EPI_TCN
-                        ve[e] = (rve + sigmoid_f(x + be) * (rstd_b * (y - mean_b * f4get(c2v[tn], e)) + f4get(c1v[tn], e))) * f4get(gv[i], e);
+                        ve[e] = (rve + sigmoid_f(x + be) * (rstd_b * y + f4get(c1v[tn], e))) * gve;   // c1 holds the folded statistics
                     }
                 }
                 v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
@@ -553,6 +613,7 @@ struct ProjNT {
             const bool nok = n < a.N;
             const unsigned nc4 = 4u * min(n, a.N - 4);
             __builtin_amdgcn_sched_barrier(0);
+            if (idx == (has_g ? NT - 2 : 0)) after_first();     // later where the gate occupies registers as well
             if (idx + 1 < NT) load_tile(idx + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -591,9 +652,9 @@ struct ProjNT {
         if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);
-        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || EPI == EPI_TCN);
+        constexpr bool RES = (EPI == EPI_BIAS_RES || EPI == EPI_RELU_MUL || IS_TCN);
         const bool has_rs = a.rowstat != nullptr;
-        const bool has_g = (EPI == EPI_TCN) && a.gmul != nullptr;
+        constexpr bool has_g = (EPI == EPI_TCN_G);
         const unsigned ldr4 = 4u * a.ldr, ldo4 = 4u * a.ldo, m_base = (unsigned)b * a.S;
         const int kh = lane >> 5, ar = lane & 31;      // accumulator layout
         const int rr = lane >> 3, rc = lane & 7;       // row-major layout
@@ -644,10 +705,14 @@ struct ProjNT {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int nc = min(ncol + 8 * g + 4 * kh, a.N - 4);
+#ifdef MSF2_DIAG_NOCONST
+                    const float4 bias = make_float4(a.prelu, a.prelu, a.prelu, a.prelu + nc), bias2 = bias, c1 = bias, c2 = bias;
+#else
                     const float4 bias = a.bias ? ld4(a.bias + nc) : zero4;
                     const float4 bias2 = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
-                    const float4 c1 = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c1 + nc) : zero4;
-                    const float4 c2 = (EPI == EPI_NORM || EPI == EPI_TCN) ? ld4(a.c2 + nc) : zero4;
+                    const float4 c1 = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c1 + nc) : zero4;
+                    const float4 c2 = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c2 + nc) : zero4;
+#endif
                     float p[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

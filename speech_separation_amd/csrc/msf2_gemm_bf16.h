@@ -196,33 +196,15 @@ template <class P> struct DmaGeom<P, 1> {
     static constexpr int BMX = 256, BNX = WC * TN * 32, NWX = BNX, NST = 4, MINB = 1;
 };
 
-// rows x 32 k of one operand: 16 rows x 64 B per wave instruction, shared evenly by the waves
-template <class P, bool IS_A, int ROWS, int NWAVES>
-__device__ __forceinline__ void bf_dma_tile(const P& prob, char* tile, int seg, int kt, int wave, int lane) {
-    constexpr int PER_WAVE = ROWS / 16 / NWAVES;
-    static_assert(PER_WAVE >= 1 && PER_WAVE * 16 * NWAVES == ROWS, "tile rows must split evenly over the waves");
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int inst = wave * PER_WAVE + i;
-        const int row = inst * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ bf_swz(row);
-        const unsigned short* src;
-        if constexpr (IS_A) src = prob.ptrA16(seg, kt, row, chunk * 8);
-        else src = prob.ptrB16(seg, kt, row, chunk * 8);
-#ifdef MSF2_DIAG_NODMA
-        if (src == nullptr)     // timing-only build: address arithmetic kept, copy never issued
-#endif
-        dma16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(tile + inst * 1024)));
-    }
-}
-
 template <class P, int BIG>
 __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
-    static_assert(BIG == 0 || !P::PAIRED, "paired-column problems keep the 128 x 128 geometry");
+    static_assert(BIG == 0 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
     constexpr int TILE_A = G::BMX * 64, TILE_B = G::BNX * 64, STAGE = TILE_A + TILE_B;   // bytes
-    constexpr int DMA_PER_TILE = (G::BMX + G::BNX) / 16 / NWAVES;                         // copies per wave and k tile
+    constexpr int PA = G::BMX / 16 / NWAVES, PB = G::BNX / 16 / NWAVES;                  // copies per wave and k tile: 16 rows x 64 B each
+    constexpr int DMA_PER_TILE = PA + PB;
+    static_assert(PA >= 1 && PB >= 1 && PA * 16 * NWAVES == G::BMX && PB * 16 * NWAVES == G::BNX, "tile rows must split evenly over the waves");
     __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + NWAVES * 4096];      // ring + one 4 KiB epilogue tile per wave
     P prob;
     if constexpr (BIG) prob.init_tile(args, G::BMX, G::NWX);
@@ -238,14 +220,33 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     // tiles of each column tile and is read from LDS.  Loaded from global memory by the epilogue itself
     // it queues behind the ~96 KB of operand copies the CU has in flight: those 16 loads cost more
     // cycles than the 32 K steps.
-    constexpr bool RESLDS = (BIG == 0) && (P::EPI_KIND == EPI_TCN);
+    constexpr bool RESLDS = (BIG == 0) && (P::NSEG == 2);
     constexpr int NRES = RESLDS ? 2 : 0;
     static_assert(!RESLDS || (STAGE == 16384 && DMA_PER_TILE == 4), "residual tiles reuse the ring stage and its copy count");
     const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG, nstream = nkt + NRES;
-    const int nrep = prob.col_tiles_here(G::NWX);
+    // the 256-row geometry is launched with one column tile per workgroup
+    constexpr bool MULTI = (BIG == 0);
+    const int nrep = MULTI ? prob.col_tiles_here(G::NWX) : 1;
     const int total = nrep * nstream;
-    P pf = prob;                 // the prefetch position runs NST-1 tiles ahead of the consumer
+    P pf = prob;                 // the prefetch position runs NST tiles ahead of the consumer
     int pf_t = 0, issued = 0;
+    // Source addresses of this wave's copies at the prefetch position.  They advance by one k tile (64 B) per
+    // issue and are derived from the problem only where the source is not linear in k: at the first k tile of
+    // a product, and where the token-shifted half of the features ends.
+    const unsigned short* pa[PA];
+    const unsigned short* pb[PB];
+    auto derive = [&](int seg, int kt) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wave * PA + i) * 16 + (lane >> 2);
+            pa[i] = pf.ptrA16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wave * PB + i) * 16 + (lane >> 2);
+            pb[i] = pf.ptrB16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+        }
+    };
     auto issue = [&]() {
         char* base = sm + (issued & (NST - 1)) * STAGE;
         if (RESLDS && pf_t >= nkt) {
@@ -261,8 +262,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         } else {
             const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
             const int kt = pf_t - seg * nk0;
-            bf_dma_tile<P, true, G::BMX, NWAVES>(pf, base, seg, kt, wave, lane);
-            bf_dma_tile<P, false, G::BNX, NWAVES>(pf, base + TILE_A, seg, kt, wave, lane);
+            if (kt == 0 || (P::A_MODE == A_SHIFT && 2 * kt == nk0)) derive(seg, kt);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                dma16(pa[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024)));
+                pa[i] += BK;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                dma16(pb[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024)));
+                pb[i] += BK;
+            }
         }
         ++issued;
         if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }
@@ -276,55 +286,70 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMA_PER_TILE) : "memory");
     };
+    // Per-column vectors of the epilogue are loaded BEFORE the ring starts: a load issued later queues behind
+    // every copy the CU has in flight.
+    constexpr int TNE = P::PAIRED ? TN / 2 : TN;
+    typedef typename P::template ColVecs<TNE> CV;
+    CV cv;
+    prob.template load_colvecs<TN>(prob.n0, wc, lane, cv);
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
+    for (int t = 0; t < NST; ++t)
         if (issued < total) issue();
+    prob.template fold_colvecs<TN>(cv);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
     int cons = 0;                // stream index of the next tile to consume (all column tiles)
 #ifdef MSF2_DIAG_STAMP
     unsigned long long tq[5] = {0, 0, 0, 0, 0}, tepi = 0;
-    unsigned long long q0, q1, q2, q3, q4;
+    unsigned long long q0, q1, q2;
 #endif
-    auto step = [&](f32x16 (&ac)[TM][TN]) {
+    // One k tile = two MFMA half steps (k 0..15 and 16..31).  The fragments of a half step are read from LDS
+    // while the MFMAs of the half step before it run:
+    //     read (t, 1) | MFMA (t, 0) | tile t + 1 landed, barrier | read (t + 1, 0) | refill slot t | MFMA (t, 1)
+    // At the barrier every wave holds the second half of tile t in registers (lgkmcnt(0)), so the slot of
+    // tile t itself is refilled: 3 tiles stay in flight behind the one being read.  The last k tile of a
+    // column tile does not read ahead (the stream continues with residual tiles or after the epilogue).
+    bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_half = [&](int st, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
+        const char* sa = sm + (cons & (NST - 1)) * STAGE;
+        const char* sb = sa + TILE_A;
+#pragma unroll
+        for (int q = 0; q < TM; ++q) fa[q] = bf_frag(sa, rowA + q * 32, st, kh);
+#pragma unroll
+        for (int q = 0; q < TN; ++q) fb[q] = bf_frag(sb, rowB + q * 32, st, kh);
+    };
+    auto mfma_half = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN], f32x16 (&ac)[TM][TN]) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                ac[tm][tn] = P::ACC_T ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tn], fa[tm], ac[tm][tn], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], ac[tm][tn], 0, 0, 0);
+    };
+    auto step = [&](f32x16 (&ac)[TM][TN], bool last) {
+        read_half(1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(fa0, fb0, ac);
+        __builtin_amdgcn_sched_barrier(0);
         MSF2_STAMP(q0)
-        wait_tile(cons);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++cons;
+        if (!last) wait_tile(cons);
         MSF2_STAMP(q1)
         __builtin_amdgcn_s_barrier();
         MSF2_STAMP(q2)
-        // All fragment reads of the step go out first and stay in flight while the address arithmetic
-        // and the copies of the refill are issued; the MFMAs then start as their operands arrive.
-        const char* sa = sm + (cons & (NST - 1)) * STAGE;
-        const char* sb = sa + TILE_A;
-        ++cons;
-        bf16x8_t af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int q = 0; q < TM; ++q) af[st][q] = bf_frag(sa, rowA + q * 32, st, kh);
-#pragma unroll
-            for (int q = 0; q < TN; ++q) bf[st][q] = bf_frag(sb, rowB + q * 32, st, kh);
-        }
+        if (!last) read_half(0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (issued < total) issue();                    // refills the slot every wave finished reading last step
+        if (issued < total) issue();                    // into the slot of the tile this step consumed
         __builtin_amdgcn_sched_barrier(0);
-        MSF2_STAMP(q3)
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    ac[tm][tn] = P::ACC_T ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[st][tn], af[st][tm], ac[tm][tn], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[st][tm], bf[st][tn], ac[tm][tn], 0, 0, 0);
+        mfma_half(fa1, fb1, ac);
         __builtin_amdgcn_sched_barrier(0);
-        MSF2_STAMP(q4)
 #ifdef MSF2_DIAG_STAMP
-        tq[0] += q1 - q0; tq[1] += q2 - q1; tq[2] += q3 - q2; tq[3] += q4 - q3; tq[4] += 1;
+        tq[0] += q1 - q0; tq[1] += q2 - q1; tq[4] += 1;
 #endif
     };
 #ifdef MSF2_DIAG_STAMP
-    unsigned long long e0 = 0, e1 = 0, e2 = 0;
+    unsigned long long e0 = 0, e1 = 0, e2 = 0, l0 = 0;
     MSF2_STAMP(e0)
 #endif
     float* stage = reinterpret_cast<float*>(sm + NST * STAGE) + wave * 1024;
@@ -338,9 +363,22 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
-        for (int t = 0; t < nk0; ++t) step(acc[0]);
-        if constexpr (P::NSEG == 2)
-            for (int t = nk0; t < nkt; ++t) step(acc[1]);
+        MSF2_STAMP(l0)
+        wait_tile(cons);
+        __builtin_amdgcn_s_barrier();
+        read_half(0, fa0, fb0);
+        if constexpr (P::NSEG == 2) {
+            for (int t = 0; t < nk0; ++t) step(acc[0], false);
+            for (int t = nk0; t < nkt - 1; ++t) step(acc[1], false);
+            step(acc[1], true);
+        } else {
+            for (int t = 0; t < nkt - 1; ++t) step(acc[0], false);
+            step(acc[0], true);
+        }
+        MSF2_STAMP(e1)
+#ifdef MSF2_DIAG_STAMP
+        tq[2] += e1 - l0;
+#endif
 #ifdef MSF2_DIAG_NOEPI
         {   // timing-only build: keep the accumulators alive with one conditional store
             float sum = 0.f;
@@ -357,19 +395,27 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
                 if (issued < total) issue();
         }
 #else
-        MSF2_STAMP(e1)
+        // The vectors of the NEXT column tile are requested after the first tile of this epilogue and first touched
+        // when it ends: by then they have long arrived, and nothing waits on them behind the copies in flight.
+        CV cvn;
+        const bool more = MULTI && rep + 1 < nrep;
+        auto next_vecs = [&]() { if (more) prob.template load_colvecs<TN>(prob.n0 + G::NWX, wc, lane, cvn); };
         if constexpr (RESLDS) {
             // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
             wait_tile(cons + 1);
             __builtin_amdgcn_s_barrier();
-            prob.template epilogue<TM, TN, true>(acc, wr, wc, lane, stage, sm + ((cons + wr) & (NST - 1)) * STAGE);
+            prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + ((cons + wr) & (NST - 1)) * STAGE, next_vecs);
             cons += NRES;
-            // every wave is done with the residual stages (and with the last k tile): refill them
+            // every wave is done with the residual stages: refill them
             __builtin_amdgcn_s_barrier();
             for (int i = 0; i < NRES; ++i)
                 if (issued < total) issue();
         } else {
-            prob.template epilogue<TM, TN>(acc, wr, wc, lane, stage);
+            prob.template epilogue_rm<TM, TN, false>(acc, wr, wc, lane, stage, cv, nullptr, next_vecs);
+        }
+        if (more) {
+            prob.template fold_colvecs<TN>(cvn);
+            cv = cvn;
         }
         MSF2_STAMP(e2)
 #ifdef MSF2_DIAG_STAMP
@@ -380,7 +426,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     }
 #ifdef MSF2_DIAG_STAMP
     MSF2_STAMP(e2)
-    if (lane == 0 && P::NSEG == 2) {     // per wave: vmcnt wait, barrier wait, reads + refill issue, MFMA issue, steps, epilogue, total
+    if (lane == 0 && P::NSEG == 2) {     // per wave: vmcnt wait, barrier wait, whole main loops, -, steps, epilogue, total
         const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if (L < 2048 && wave < 4) {
             unsigned long long* o = g_stamp + (L * 4 + wave) * 4;
