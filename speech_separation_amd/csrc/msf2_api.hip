@@ -178,11 +178,13 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
     }
     {
-        SimArgs a = {quad_q, quad_k, w.P, c.S, w.G};
+        // bf16 mode: scores and lin_q exist as bf16 only (the values the contraction would round them to anyway)
+        SimArgs a = {quad_q, quad_k, w.P, c.S, w.G, hu16 ? reinterpret_cast<unsigned short*>(w.P) : nullptr};
         launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
     }
     {
-        AttnOutArgs a = {w.P, lin_q, hsrc, ldhu, w.kv, o, c.S, w.G, E, o16};
+        AttnOutArgs a = {w.P, lin_q, hsrc, ldhu, w.kv, o, c.S, w.G, E, o16,
+                         reinterpret_cast<const unsigned short*>(w.P), reinterpret_cast<const unsigned short*>(lin_q)};
         if (hu16) launch_gemm<AttnOutT<true>>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
         else launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
     }

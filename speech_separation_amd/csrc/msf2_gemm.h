@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
     MSF2_STAMP(tk1)
 #endif
     // main loop ended with a barrier: LDS is free
-    if constexpr (P::ACC_T) {
+    if constexpr (P::EPI_RM) {
         typename P::template ColVecs<(P::PAIRED ? TN / 2 : TN)> cv;
         prob.template load_colvecs<TN>(prob.n0, wc, lane, cv);
         prob.template fold_colvecs<TN>(cv);
@@ -353,8 +353,10 @@ struct ProjNT {
     static constexpr bool IS_TCN = (EPI == EPI_TCN || EPI == EPI_TCN_G);
     static constexpr int NSEG = IS_TCN ? 2 : 1;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
+    static constexpr bool A_BF16 = false;
     static constexpr bool B_BF16 = true;    // bf16 kernels read W as bf16
     static constexpr bool ACC_T = true;     // accumulators transposed: MFMA(weight fragment, activation fragment)
+    static constexpr bool EPI_RM = true;    // the fp32 kernel finishes tiles with epilogue_rm
     Args a;
     int b, s0, n0;
     __device__ void init(const Args& args) {
@@ -787,12 +789,13 @@ struct SimArgs {
     const float* q;  const float* k;   // [B*S][128]
     float* P;                          // [B*G][256][256]
     int S, G;
+    unsigned short* P16;               // when set, the scores are written as bf16 here instead of fp32 to P
 };
 struct AttnSim {
     typedef SimArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
-    static constexpr bool B_BF16 = false;
-    static constexpr bool ACC_T = false;
+    static constexpr bool A_BF16 = false, B_BF16 = false;
+    static constexpr bool ACC_T = false, EPI_RM = false;
     Args a;
     int b, g, m0, n0;
     __device__ void init(const Args& args) {
@@ -819,7 +822,8 @@ struct AttnSim {
                     const int i = m0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
                     const int j = n0 + MSF2_ACC_COL(wc, TN, tn, lane);
                     const float x = fmaxf(acc[0][tm][tn][reg], 0.f);
-                    P[i * MSF2_GROUP + j] = x * x;
+                    if (a.P16) a.P16[(long)blockIdx.z * MSF2_GROUP * MSF2_GROUP + i * MSF2_GROUP + j] = (unsigned short)pk_bf16_1(x * x);
+                    else P[i * MSF2_GROUP + j] = x * x;
                 }
     }
 };
@@ -840,8 +844,9 @@ template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct LinKVT {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
+    static constexpr bool A_BF16 = false;
     static constexpr bool B_BF16 = false;
-    static constexpr bool ACC_T = false;
+    static constexpr bool ACC_T = false, EPI_RM = false;
     Args a;
     int b, k0, k1, n0;
     __device__ void init(const Args& args) {
@@ -897,13 +902,17 @@ struct AttnOutArgs {
     float* o;                        // [B*S][E]; may be null when o16 is given
     int S, G, E;
     unsigned short* o16;             // optional bf16 copy of o
+    const unsigned short* P16;       // HU16: bf16 scores [B*G][256][256] and bf16 lin_q [B*S][128], read instead of P / lq
+    const unsigned short* lq16;
 };
 template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct AttnOutT {
     typedef AttnOutArgs Args;
     static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
+    static constexpr bool A_BF16 = HU16;       // the bf16 kernel then reads P16 / lq16 instead of P / lq
     static constexpr bool B_BF16 = false;
-    static constexpr bool ACC_T = false;
+    static constexpr bool ACC_T = true;      // MFMA(value fragment, score fragment): a lane owns 4 consecutive output columns
+    static constexpr bool EPI_RM = false;
     static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
     int z, b, g, m0, j0;
@@ -923,6 +932,13 @@ struct AttnOutT {
         const float* pl = a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
         return kt < KT_QUAD ? pq : pl;               // kt is wave-uniform
     }
+    __device__ const unsigned short* ptrA16(int, int kt, int r, int ko) const {
+        const int i = m0 + r;
+        const unsigned short* pq = a.P16 + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
+        const int s = min(g * MSF2_GROUP + i, a.S - 1);
+        const unsigned short* pl = a.lq16 + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
+        return kt < KT_QUAD ? pq : pl;               // kt is wave-uniform
+    }
     __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
         const int s = g * MSF2_GROUP + kt * BK + ko;
@@ -938,46 +954,70 @@ struct AttnOutT {
             return mul4(ld4(kt < KT_QUAD ? a.hu + oq : pl), m);
         }
     }
+    // Accumulators are transposed (ACC_T): each 32 x 32 tile goes through the wave's 4 KiB LDS tile into row-major
+    // registers (lane l: rows 8 i + (l >> 3), columns 4 (l & 7) + 0..3), so v, u and o move as 8-byte (bf16) or
+    // 16-byte (fp32) vectors, 8 rows x 32 columns per wave instruction.  All v / u loads are issued up front
+    // from clamped rows; only the stores are predicated.
     template <int TM, int TN>
-    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
+    __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float* stage) const {
+        static_assert(TM == 1 && WC == 1, "one 32-row slab per wave");
         const unsigned ldh4 = 4u * a.ldhu, e4 = 4u * a.E;
+        const int kh = lane >> 5, ar = lane & 31;      // accumulator layout
+        const int rr = lane >> 3, rc = lane & 7;       // row-major layout
+        unsigned mrow[4];
+        bool ok[4];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            unsigned mrow[16];
-            bool ok[16];
+        for (int i = 0; i < 4; ++i) {
+            const int s = g * MSF2_GROUP + m0 + wr * 32 + 8 * i + rr;
+            ok[i] = s < a.S;
+            mrow[i] = (unsigned)b * a.S + min(s, a.S - 1);
+        }
+        float4 v[TN / 2][4], u[TN / 2][4];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int s = g * MSF2_GROUP + m0 + MSF2_ACC_ROW(wr, TM, tm, reg, lane);
-                ok[reg] = s < a.S;
-                mrow[reg] = (unsigned)b * a.S + min(s, a.S - 1);
-            }
-            float v[TN / 2][16], u[TN / 2][16];
+        for (int tn = 0; tn < TN / 2; ++tn) {
+            const unsigned j4 = 4u * (j0 + tn * 32 + 4 * rc);
 #pragma unroll
-            for (int tn = 0; tn < TN / 2; ++tn) {
-                const unsigned j4 = 4u * (j0 + MSF2_ACC_COL(wc, TN, tn, lane));
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    if constexpr (HU16) {
-                        const char* h16 = reinterpret_cast<const char*>(a.hu);
-                        v[tn][reg] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(h16 + ((mrow[reg] * ldh4 + j4) >> 1)) << 16);
-                        u[tn][reg] = __builtin_bit_cast(float, (unsigned)*reinterpret_cast<const unsigned short*>(h16 + ((mrow[reg] * ldh4 + e4 + j4) >> 1)) << 16);
-                    } else {
-                        v[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + j4);
-                        u[tn][reg] = ldg_off(a.hu, mrow[reg] * ldh4 + e4 + j4);
-                    }
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (HU16) {
+                    v[tn][i] = ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu), (mrow[i] * ldh4 + j4) >> 1);
+                    u[tn][i] = ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu), (mrow[i] * ldh4 + e4 + j4) >> 1);
+                } else {
+                    v[tn][i] = ldg4_off(a.hu, mrow[i] * ldh4 + j4);
+                    u[tn][i] = ldg4_off(a.hu, mrow[i] * ldh4 + e4 + j4);
                 }
             }
+        }
+        auto transpose = [&](const f32x16& t, float4 (&o)[4]) {
 #pragma unroll
-            for (int tn = 0; tn < TN / 2; ++tn) {
-                const unsigned j4 = 4u * (j0 + MSF2_ACC_COL(wc, TN, tn, lane));
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(stage + (ar * 8 + ((2 * q + kh) ^ (ar & 7))) * 4) =
+                    make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float av = acc[0][tm][tn][reg], au = acc[0][tm][tn + TN / 2][reg];
-                    if (ok[reg]) {
-                        const float r = (au * v[tn][reg]) * sigmoid_f(av * u[tn][reg]);
-                        if (a.o) stg_off(a.o, mrow[reg] * e4 + j4, r);
-                        if (a.o16) *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(a.o16) + ((mrow[reg] * e4 + j4) >> 1)) = (unsigned short)pk_bf16_1(r);
-                    }
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr;
+                o[i] = *reinterpret_cast<const float4*>(stage + (row * 8 + (rc ^ (row & 7))) * 4);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+#pragma unroll
+        for (int tn = 0; tn < TN / 2; ++tn) {
+            float4 av[4], au[4];
+            transpose(acc[0][0][tn], av);
+            transpose(acc[0][0][tn + TN / 2], au);
+            const unsigned j4 = 4u * (j0 + tn * 32 + 4 * rc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 r;
+                r.x = (au[i].x * v[tn][i].x) * sigmoid_f(av[i].x * u[tn][i].x);
+                r.y = (au[i].y * v[tn][i].y) * sigmoid_f(av[i].y * u[tn][i].y);
+                r.z = (au[i].z * v[tn][i].z) * sigmoid_f(av[i].z * u[tn][i].z);
+                r.w = (au[i].w * v[tn][i].w) * sigmoid_f(av[i].w * u[tn][i].w);
+                if (ok[i]) {
+                    if (a.o) stg4_off(a.o, mrow[i] * e4 + j4, r);
+                    if (a.o16) stg4_bf16_off(a.o16, (mrow[i] * e4 + j4) >> 1, r);
                 }
             }
         }

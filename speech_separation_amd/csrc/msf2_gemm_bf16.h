@@ -48,7 +48,9 @@ __device__ __forceinline__ void bf_fetch(const P& prob, int kt, int tid, float4 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = tid + 256 * i;
-            const uint4 v = *reinterpret_cast<const uint4*>(prob.ptrB16(SEG, kt, e >> 2, (e & 3) * 8));
+            uint4 v;
+            if constexpr (IS_A) v = *reinterpret_cast<const uint4*>(prob.ptrA16(SEG, kt, e >> 2, (e & 3) * 8));
+            else v = *reinterpret_cast<const uint4*>(prob.ptrB16(SEG, kt, e >> 2, (e & 3) * 8));
             r[i] = __builtin_bit_cast(float4, v);
         }
     } else {
@@ -97,7 +99,7 @@ __device__ __forceinline__ bf16x8_t bf_frag(const char* tile, int row, int step,
 }
 
 template <class P> struct BfSrc {
-    static constexpr int A = (P::A_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32;
+    static constexpr int A = P::A_BF16 ? SRC_KC_BF16 : ((P::A_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32);
     static constexpr int B = P::B_BF16 ? SRC_KC_BF16 : ((P::B_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32);
 };
 
@@ -265,11 +267,17 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
             if (kt == 0 || (P::A_MODE == A_SHIFT && 2 * kt == nk0)) derive(seg, kt);
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_A)
+                if (pa[i] == nullptr)     // timing-only builds: address arithmetic kept, copy never issued
+#endif
                 dma16(pa[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024)));
                 pa[i] += BK;
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_B)
+                if (pb[i] == nullptr)
+#endif
                 dma16(pb[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024)));
                 pb[i] += BK;
             }

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(128) void dwconv17_bf16_kernel(const unsigned short
 // ---- OffsetScale + rotary -> quad_q/256, lin_q, quad_k, lin_k ----------------
 // qk: [M] rows, row stride ld (already offset to the qk columns).  q4: [4][M][128].
 // grid ceil(M/4), block 256 (64 lanes = 64 feature pairs of one row)
-// IN16: qk points at bf16 values (same indexing).
+// IN16 (bf16 mode): qk points at bf16 values (same indexing) and lin_q is written as bf16.
 template <bool IN16>
 __global__ __launch_bounds__(256) void qk_prep_kernel(const void* __restrict__ qk_, int ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -285,7 +285,10 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(const void* __restrict__ q
         o.x = y0 * c - y1 * sn;
         o.y = y1 * c + y0 * sn;
         if (h == 0) { o.x *= (1.0f / MSF2_GROUP); o.y *= (1.0f / MSF2_GROUP); }
-        *reinterpret_cast<float2*>(q4 + ((long)h * M + m) * MSF2_QK_DIM + 2 * p) = o;
+        if (IN16 && h == 1)      // bf16 mode: lin_q is only ever a bf16 contraction operand; its slot holds [M][128] bf16
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(q4 + (long)M * MSF2_QK_DIM) + m * MSF2_QK_DIM + 2 * p) = pk_bf16_pair(o.x, o.y);
+        else
+            *reinterpret_cast<float2*>(q4 + ((long)h * M + m) * MSF2_QK_DIM + 2 * p) = o;
     }
 }
 

@@ -31,7 +31,7 @@ epi = (b[..., 0] >> np.uint64(20)).astype(np.float64)
 tot = b[..., 1].astype(np.float64)
 ok = steps > 0
 print("blocks with data", ok[:, 0].sum(), "steps per block", steps[ok].mean())
-for i, n in enumerate(("vmcnt wait", "barrier wait", "reads+refill", "mfma issue")):
+for i, n in enumerate(("vmcnt wait", "barrier wait", "whole step")):
     v = a[..., i][ok] / steps[ok]
     print(f"{n:14s} cycles/step: mean {v.mean():7.0f}  p10 {np.percentile(v,10):7.0f}  p90 {np.percentile(v,90):7.0f}")
-print(f"epilogues cycles/block: {epi[ok].mean():9.0f}   whole block: {tot[ok].mean():9.0f}   main loop: {(a.sum(-1)[ok]).mean():9.0f}")
+print(f"epilogues cycles/block: {epi[ok].mean():9.0f}   whole block: {tot[ok].mean():9.0f}   main loops: {(a[..., 2][ok]).mean():9.0f}")
