@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / P::WC, wc = wave % P::WC;
     constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
-    f32x16 acc[P::NSEG][TM][TN];
+    f32x16 acc[P::NACC][TM][TN];     // NACC accumulator sets; the K segments of a problem with NACC = 1 share one
 #pragma unroll
-    for (int s = 0; s < P::NSEG; ++s)
+    for (int s = 0; s < P::NACC; ++s)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
     run_segment<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wave, wr, wc);
-    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wave, wr, wc);
+    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[P::NACC - 1], tid, lane, wave, wr, wc);
 #ifdef MSF2_DIAG_NOEPI
     {   // timing-only build: keep the accumulators alive with one store per thread
         float sum = 0.f;
-        for (int s = 0; s < P::NSEG; ++s)
+        for (int s = 0; s < P::NACC; ++s)
             for (int tm = 0; tm < TM; ++tm)
                 for (int tn = 0; tn < TN; ++tn)
                     for (int r = 0; r < 16; ++r) sum += acc[s][tm][tn][r];
@@ -351,7 +351,7 @@ struct ProjNT {
     static constexpr int EPI_KIND = EPI, A_MODE = AMODE;
     static constexpr int WR = PAIRED ? 4 : 2, WC = PAIRED ? 1 : 2;
     static constexpr bool IS_TCN = (EPI == EPI_TCN || EPI == EPI_TCN_G);
-    static constexpr int NSEG = IS_TCN ? 2 : 1;
+    static constexpr int NSEG = IS_TCN ? 2 : 1, NACC = NSEG;
     static constexpr int A_ORI = ORI_KC, B_ORI = ORI_KC;
     static constexpr bool A_BF16 = false;
     static constexpr bool B_BF16 = true;    // bf16 kernels read W as bf16
@@ -793,7 +793,7 @@ struct SimArgs {
 };
 struct AttnSim {
     typedef SimArgs Args;
-    static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
+    static constexpr int WR = 2, WC = 2, NSEG = 1, NACC = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
     static constexpr bool A_BF16 = false, B_BF16 = false;
     static constexpr bool ACC_T = false, EPI_RM = false;
     Args a;
@@ -843,7 +843,7 @@ struct LinKVArgs {
 template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct LinKVT {
     typedef LinKVArgs Args;
-    static constexpr int WR = 2, WC = 2, NSEG = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
+    static constexpr int WR = 2, WC = 2, NSEG = 1, NACC = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
     static constexpr bool A_BF16 = false;
     static constexpr bool B_BF16 = false;
     static constexpr bool ACC_T = false, EPI_RM = false;
@@ -908,12 +908,12 @@ struct AttnOutArgs {
 template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct AttnOutT {
     typedef AttnOutArgs Args;
-    static constexpr int WR = 4, WC = 1, NSEG = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
+    // two K segments into ONE accumulator set: 0 = scores x the group's value rows, 1 = lin_q x KV
+    static constexpr int WR = 4, WC = 1, NSEG = 2, NACC = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
     static constexpr bool A_BF16 = HU16;       // the bf16 kernel then reads P16 / lq16 instead of P / lq
     static constexpr bool B_BF16 = false;
     static constexpr bool ACC_T = true;      // MFMA(value fragment, score fragment): a lane owns 4 consecutive output columns
     static constexpr bool EPI_RM = false;
-    static constexpr int KT_QUAD = MSF2_GROUP / BK;   // K steps fed by P / group rows; the rest by lin_q / KV
     Args a;
     int z, b, g, m0, j0;
     __device__ void init(const Args& args) {
@@ -924,35 +924,28 @@ struct AttnOutT {
         b = z / a.G;  g = z % a.G;
         m0 = (rest % gridDim.y) * BM;  j0 = jt * (BN / 2);
     }
-    __device__ int nk(int) const { return (MSF2_GROUP + MSF2_QK_DIM) / BK; }
-    __device__ const float* ptrA(int, int kt, int r, int ko) const {
+    __device__ int nk(int seg) const { return (seg == 0 ? MSF2_GROUP : MSF2_QK_DIM) / BK; }
+    // seg is a compile-time constant at every call site: each K loop reads one source only
+    __device__ const float* ptrA(int seg, int kt, int r, int ko) const {
         const int i = m0 + r;
-        const float* pq = a.P + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
+        if (seg == 0) return a.P + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
         const int s = min(g * MSF2_GROUP + i, a.S - 1);
-        const float* pl = a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
-        return kt < KT_QUAD ? pq : pl;               // kt is wave-uniform
+        return a.lq + ((long)b * a.S + s) * MSF2_QK_DIM + kt * BK + ko;
     }
-    __device__ const unsigned short* ptrA16(int, int kt, int r, int ko) const {
+    __device__ const unsigned short* ptrA16(int seg, int kt, int r, int ko) const {
         const int i = m0 + r;
-        const unsigned short* pq = a.P16 + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
+        if (seg == 0) return a.P16 + ((long)z * MSF2_GROUP + i) * MSF2_GROUP + kt * BK + ko;
         const int s = min(g * MSF2_GROUP + i, a.S - 1);
-        const unsigned short* pl = a.lq16 + ((long)b * a.S + s) * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko;
-        return kt < KT_QUAD ? pq : pl;               // kt is wave-uniform
+        return a.lq16 + ((long)b * a.S + s) * MSF2_QK_DIM + kt * BK + ko;
     }
-    __device__ float4 fetchB(int, int kt, int c, int ko) const {
+    __device__ float4 fetchB(int seg, int kt, int c, int ko) const {
         const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
+        if (seg == 1) return ld4(a.kv + ((long)b * MSF2_QK_DIM + kt * BK + ko) * (2 * a.E) + e);
         const int s = g * MSF2_GROUP + kt * BK + ko;
         const long oq = ((long)b * a.S + min(s, a.S - 1)) * a.ldhu + e;
-        const float* pl = a.kv + ((long)b * MSF2_QK_DIM + (kt - KT_QUAD) * BK + ko) * (2 * a.E) + e;
-        const float m = (kt < KT_QUAD && s >= a.S) ? 0.f : 1.f;   // value rows past the utterance end are zero
-        if constexpr (HU16) {
-            // kt is wave-uniform: one of the two loads is issued from a valid dummy address and discarded
-            const float4 q = ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu) + (kt < KT_QUAD ? oq : 0), 0u);
-            const float4 l = ld4(kt < KT_QUAD ? a.kv : pl);
-            return mul4(kt < KT_QUAD ? q : l, m);
-        } else {
-            return mul4(ld4(kt < KT_QUAD ? a.hu + oq : pl), m);
-        }
+        const float m = (s >= a.S) ? 0.f : 1.f;      // value rows past the utterance end are zero
+        if constexpr (HU16) return mul4(ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu) + oq, 0u), m);
+        else return mul4(ld4(a.hu + oq), m);
     }
     // Accumulators are transposed (ACC_T): each 32 x 32 tile goes through the wave's 4 KiB LDS tile into row-major
     // registers (lane l: rows 8 i + (l >> 3), columns 4 (l & 7) + 0..3), so v, u and o move as 8-byte (bf16) or

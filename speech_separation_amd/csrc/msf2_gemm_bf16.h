@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Arg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / P::WC, wc = wave % P::WC;
     constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
-    f32x16 acc[P::NSEG][TM][TN];
+    f32x16 acc[P::NACC][TM][TN];
 #pragma unroll
-    for (int s = 0; s < P::NSEG; ++s)
+    for (int s = 0; s < P::NACC; ++s)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Arg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
     run_segment_bf16<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wr, wc);
-    if constexpr (P::NSEG == 2) run_segment_bf16<P, 1, TM, TN>(prob, smA, smB, acc[1], tid, lane, wr, wc);
+    if constexpr (P::NSEG == 2) run_segment_bf16<P, 1, TM, TN>(prob, smA, smB, acc[P::NACC - 1], tid, lane, wr, wc);
     prob.template epilogue<TM, TN>(acc, wr, wc, lane, reinterpret_cast<float*>(smA) + (tid >> 6) * 1024);
 }
 
