@@ -844,6 +844,7 @@ template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct LinKVT {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, NACC = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
+    static constexpr int BF16_MIN_BLOCKS = HU16 ? 4 : 3;
     static constexpr bool A_BF16 = false;
     static constexpr bool B_BF16 = false;
     static constexpr bool ACC_T = false, EPI_RM = false;
@@ -911,6 +912,7 @@ struct AttnOutT {
     // two K segments into ONE accumulator set: 0 = scores x the group's value rows, 1 = lin_q x KV
     static constexpr int WR = 4, WC = 1, NSEG = 2, NACC = 1, A_ORI = ORI_KC, B_ORI = ORI_RC;
     static constexpr bool A_BF16 = HU16;       // the bf16 kernel then reads P16 / lq16 instead of P / lq
+    static constexpr int BF16_MIN_BLOCKS = HU16 ? 4 : 3;  // bf16 kernel, all-bf16 operands: 128 registers, 4 workgroups (32 KiB of LDS each) per CU
     static constexpr bool B_BF16 = false;
     static constexpr bool ACC_T = true;      // MFMA(value fragment, score fragment): a lane owns 4 consecutive output columns
     static constexpr bool EPI_RM = false;

@@ -151,8 +151,12 @@ __device__ __forceinline__ void run_segment_bf16(const P& prob, char* smA, char*
     __syncthreads();
 }
 
+// workgroups per CU the register allocation must allow (P::BF16_MIN_BLOCKS where a problem states one, else 2)
+template <class P, class = void> struct Bf16MinBlocks { static constexpr int V = 2; };
+template <class P> struct Bf16MinBlocks<P, decltype((void)P::BF16_MIN_BLOCKS)> { static constexpr int V = P::BF16_MIN_BLOCKS; };
+
 template <class P>
-__global__ __launch_bounds__(256, 2) void gemm_kernel_bf16(const typename P::Args args) {
+__global__ __launch_bounds__(256, Bf16MinBlocks<P>::V) void gemm_kernel_bf16(const typename P::Args args) {
     __shared__ __attribute__((aligned(16))) char smA[2 * BF_TILE];
     __shared__ __attribute__((aligned(16))) char smB[2 * BF_TILE];
     P prob;
