@@ -73,8 +73,9 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         return;
     }
     const TimedLaunch timed_(P::NSEG == 2 ? c.st : nullptr, P::NSEG == 2);
-    // (the two-product form of the DMA kernel streams the bf16 residual with the operands: it needs res16)
-    if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && (EPI != EPI_TCN_G || a.gmul16)))) {
+    // (the two-product form of the DMA kernel streams the bf16 residual with the operands, reads the column vector
+    // with the statistics folded in and writes bf16 only: it needs res16, c1f and out16 without out)
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && a.c1f && a.out16 && !a.out && (EPI != EPI_TCN_G || a.gmul16)))) {
         // One workgroup walks 2 column tiles of its row tile: its ring then prefetches the second tile
         // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
         // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all
@@ -86,9 +87,10 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
             // 256-row tiles, one 8-wave workgroup per CU, when that still gives every CU several tiles
             typedef DmaGeom<P, 1> G;
             dim3 gb(cdiv(a.N, G::BNX), cdiv(c.S, G::BMX), c.B);
-            // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 2 % slower for the
-            // two-product TCN contraction and the N = 2176 projection, which keep the 128 x 128 form
-            const bool want = a.N <= 1024 && getenv("MSF2_NO_BIG") == nullptr;
+            // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 5 % for the N = 2176 one
+            // (its ninth 256-column tile half empty); the two-product TCN contraction keeps the 128 x 128 form
+            static const int big_maxn = getenv("MSF2_BIG_MAXN") ? atoi(getenv("MSF2_BIG_MAXN")) : 4096;
+            const bool want = a.N <= big_maxn && getenv("MSF2_NO_BIG") == nullptr;
             if (want && (long)gb.x * gb.y * gb.z >= 1024) {
                 al.ncol_loop = 1;                 // 256 columns per tile already
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);
@@ -112,8 +114,9 @@ static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N,
     return a;
 }
 
-static void launch_stats_finalize(const Ctx& c, const float* part, int nblk, long count_per_b, float eps, float* stats) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(c.B), dim3(64), 0, c.st, part, nblk, (double)count_per_b, eps, stats);
+static void launch_stats_finalize(const Ctx& c, const float* part, int nblk, long count_per_b, float eps, float* stats,
+                                  const float* c1 = nullptr, const float* c2 = nullptr, float* c1f = nullptr, int C = 0) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(c.B), dim3(64), 0, c.st, part, nblk, (double)count_per_b, eps, stats, c1, c2, c1f, C);
 }
 
 template <int MODE>
@@ -192,7 +195,7 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
 
 // ---- gated TCN block ----------------------------------------------------------
 struct TcnWs {
-    float *rowstat, *g, *h0, *h1, *t, *part, *bstat;
+    float *rowstat, *g, *h0, *h1, *t, *part, *bstat, *c1f;
     unsigned short *g16, *h16a, *h16b, *t16;     // bf16 mode: the gate and the operand images of h and t
     int nblk;
 };
@@ -207,6 +210,7 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
         w.h1 = ar.take<float>(M * C);
     }
     if (prec == MSF2_PREC_BF16) {
+        w.c1f = ar.take<float>((long)B * C);
         w.g16 = ar.take<unsigned short>(M * C);
         w.h16a = ar.take<unsigned short>(M * C);
         w.h16b = ar.take<unsigned short>(M * C);
@@ -249,10 +253,10 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned 
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
         launch_stage_a_bf16(c, w, h16, tw, C, 1 << j);
-        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
+        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat, tw.c1, tw.c2, w.c1f, C);
         ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
-        a.bstat = w.bstat; a.res16 = h16; a.ldr = C; a.out16 = hn16;
+        a.bstat = w.bstat; a.c1f = w.c1f; a.res16 = h16; a.ldr = C; a.out16 = hn16;
         if (j == MSF2_TCN_DEPTH - 1) {               // the last block hands g * h to proj_out
             a.gmul16 = w.g16;
             launch_proj<A_PLAIN, EPI_TCN_G>(c, a);

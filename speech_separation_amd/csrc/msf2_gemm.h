@@ -329,6 +329,7 @@ struct ProjArgs {
     const float* bias;  const float* bias2;  const float* c1;  const float* c2;
     const float* rowstat;   // [B*S] inverse norms, or [B*S][2] (mean, rstd)
     const float* bstat;     // [B][2] (mean, rstd)
+    const float* c1f;       // EPI_TCN, DMA kernel: [B][N] = c1 - rstd_b * mean_b * c2, written by stats_finalize_kernel
     const float* res;  int ldr;
     const float* pe;        // [S][N]
     const float* gmul;      // EPI_TCN_G: elementwise gate multiplied onto the result, [B*S][ldo]
@@ -450,7 +451,8 @@ struct ProjNT {
     // that count outstanding memory operations rely on COLVEC_LOADS.
     template <int TNE> struct ColVecs { float4 bias[TNE], bias2[TNE], c1[TNE], c2[TNE]; };
     static constexpr int COLVEC_KINDS = 1 + ((EPI == EPI_NORM || IS_TCN) ? 2 : 0) + ((EPI == EPI_TANH_SIG) ? 1 : 0);
-    template <int TN>
+    // FOLDED: c1 comes from a.c1f (statistics already folded in), c2 is not read.
+    template <int TN, bool FOLDED = false>
     __device__ void load_colvecs(int n_origin, int wc, int lane, ColVecs<(PAIRED ? TN / 2 : TN)>& cv) const {
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -460,13 +462,18 @@ struct ProjNT {
             const int nc = min(n_origin + wc * (TN * 32) + tn * 32 + 4 * rc, a.N - 4);
             cv.bias[tn] = ld4((a.bias ? a.bias : a.W) + nc);
             cv.bias2[tn] = (EPI == EPI_TANH_SIG) ? ld4(a.bias2 + nc) : zero4;
-            cv.c1[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c1 + nc) : zero4;
-            cv.c2[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c2 + nc) : zero4;
+            if constexpr (FOLDED) {
+                cv.c1[tn] = ld4(a.c1f + (long)b * a.N + nc);
+                cv.c2[tn] = zero4;
+            } else {
+                cv.c1[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c1 + nc) : zero4;
+                cv.c2[tn] = (EPI == EPI_NORM || IS_TCN) ? ld4(a.c2 + nc) : zero4;
+            }
         }
     }
     // second half of load_colvecs: everything that reads the loaded values (the caller may put independent
     // memory traffic between the two)
-    template <int TN>
+    template <int TN, bool FOLDED = false>
     __device__ void fold_colvecs(ColVecs<(PAIRED ? TN / 2 : TN)>& cv) const {
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -475,7 +482,7 @@ struct ProjNT {
 #pragma unroll
         for (int tn = 0; tn < TNE; ++tn) {
             if (!a.bias) cv.bias[tn] = zero4;
-            if constexpr (IS_TCN) {
+            if constexpr (IS_TCN && !FOLDED) {
                 const float k = rstd_b * mean_b;
                 cv.c1[tn] = make_float4(cv.c1[tn].x - k * cv.c2[tn].x, cv.c1[tn].y - k * cv.c2[tn].y,
                                         cv.c1[tn].z - k * cv.c2[tn].z, cv.c1[tn].w - k * cv.c2[tn].w);
@@ -572,6 +579,7 @@ struct ProjNT {
             if constexpr (IS_TCN) transpose(acc[NSEG - 1][tm][tn], y4);
             if constexpr (EPI == EPI_TANH_SIG) transpose(acc[0][tm][tn + TN / 2], y4);
             float4 v[4], w2[4];
+            uint2 vp[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float mu = (EPI == EPI_NORM && has_rs) ? r1[i] : mean_b, rs = (EPI == EPI_NORM && has_rs) ? r0[i] : rstd_b;
@@ -605,8 +613,13 @@ struct ProjNT {
                         ve[e] = (rve + sigmoid_f(x + be) * (rstd_b * y + f4get(c1v[tn], e))) * gve;   // c1 holds the folded statistics
                     }
                 }
-                v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
-                w2[i] = make_float4(we[0], we[1], we[2], we[3]);
+                if constexpr (RESLDS) {        // bf16 output only (the DMA kernel's two-product form): packed at once
+                    vp[i].x = pk_bf16_2(ve[0], ve[1]);
+                    vp[i].y = pk_bf16_2(ve[2], ve[3]);
+                } else {
+                    v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+                    w2[i] = make_float4(we[0], we[1], we[2], we[3]);
+                }
             }
             unsigned mrow[4];
             bool ok[4];
@@ -615,13 +628,17 @@ struct ProjNT {
             const bool nok = n < a.N;
             const unsigned nc4 = 4u * min(n, a.N - 4);
             __builtin_amdgcn_sched_barrier(0);
-            if (idx == (has_g ? NT - 2 : 0)) after_first();     // later where the gate occupies registers as well
+            if (idx == 0) after_first();
             if (idx + 1 < NT) load_tile(idx + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (ok[i] && nok) {
                     const unsigned off = mrow[i] * ldo4 + nc4;
+                    if constexpr (RESLDS) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out16) + (off >> 1)) = vp[i];
+                        continue;
+                    }
                     if (a.out) stg4_off(a.out, off, v[i]);
                     if (EPI == EPI_NORM && a.out2) stg4_off(a.out2, off, v[i]);
                     if (EPI == EPI_RELU_MUL && a.out2) stg4_off(a.out2, off, w2[i]);

@@ -301,13 +301,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     // Per-column vectors of the epilogue are loaded BEFORE the ring starts: a load issued later queues behind
     // every copy the CU has in flight.
     constexpr int TNE = P::PAIRED ? TN / 2 : TN;
+    constexpr bool FOLDED = (P::NSEG == 2);      // the two-product form reads c1 with the utterance statistics folded in
     typedef typename P::template ColVecs<TNE> CV;
     CV cv;
-    prob.template load_colvecs<TN>(prob.n0, wc, lane, cv);
+    prob.template load_colvecs<TN, FOLDED>(prob.n0, wc, lane, cv);
 #pragma unroll
     for (int t = 0; t < NST; ++t)
         if (issued < total) issue();
-    prob.template fold_colvecs<TN>(cv);
+    prob.template fold_colvecs<TN, FOLDED>(cv);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
     int cons = 0;                // stream index of the next tile to consume (all column tiles)
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         // when it ends: by then they have long arrived, and nothing waits on them behind the copies in flight.
         CV cvn;
         const bool more = MULTI && rep + 1 < nrep;
-        auto next_vecs = [&]() { if (more) prob.template load_colvecs<TN>(prob.n0 + G::NWX, wc, lane, cvn); };
+        auto next_vecs = [&]() { if (more) prob.template load_colvecs<TN, FOLDED>(prob.n0 + G::NWX, wc, lane, cvn); };
         if constexpr (RESLDS) {
             // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
             wait_tile(cons + 1);
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
             prob.template epilogue_rm<TM, TN, false>(acc, wr, wc, lane, stage, cv, nullptr, next_vecs);
         }
         if (more) {
-            prob.template fold_colvecs<TN>(cvn);
+            prob.template fold_colvecs<TN, FOLDED>(cvn);
             cv = cvn;
         }
         MSF2_STAMP(e2)

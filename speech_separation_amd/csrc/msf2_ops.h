@@ -57,8 +57,12 @@ __global__ __launch_bounds__(256) void encoder_kernel(const float* __restrict__ 
 
 // ---- (mean, rstd) of one utterance from block partials ----------------------
 // grid B, block 64.  stats: [B][2]
+// Optionally also folds the statistics into a per-column vector of the contraction that consumes them:
+// c1f[b][n] = c1[n] - rstd_b * mean_b * c2[n]  (C columns; skipped when c1f is null).
 __global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restrict__ part, int nblk, double count,
-                                                            float eps, float* __restrict__ stats) {
+                                                            float eps, float* __restrict__ stats,
+                                                            const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            float* __restrict__ c1f, int C) {
     const int b = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 64) {
@@ -67,12 +71,17 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(const float* __restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const double mean = s / count;      // every lane holds the full sums
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_f = (float)mean, rstd_f = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0) {
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[2 * b] = (float)mean;
-        stats[2 * b + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[2 * b] = mean_f;
+        stats[2 * b + 1] = rstd_f;
+    }
+    if (c1f) {
+        const float k = rstd_f * mean_f;
+        for (int i = threadIdx.x; i < C; i += 64) c1f[(long)b * C + i] = c1[i] - k * c2[i];
     }
 }
 
