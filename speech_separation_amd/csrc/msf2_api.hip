@@ -124,10 +124,17 @@ static void launch_rowstat(const Ctx& c, const float* x, int ldx, float* out, in
     hipLaunchKernelGGL(rowstat_kernel<MODE>, dim3(cdiv(c.M, 4)), dim3(256), 0, c.st, x, ldx, out, c.M, c.S, C, shift, eps);
 }
 
-static void launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate,
-                            unsigned short* y16 = nullptr) {
+// ln_out: optional [M][2] LayerNorm statistics (mean, rstd; eps 1e-5) of the result rows, written by the same kernel
+// when a row fits one block (C <= 512).  Returns whether they were written.
+static bool launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate,
+                            unsigned short* y16 = nullptr, float* ln_out = nullptr) {
     dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
-    hipLaunchKernelGGL(dwconv17_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16);
+    if (ln_out && grid.x == 1) {
+        hipLaunchKernelGGL(dwconv17_kernel<true>, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16, ln_out, 1e-5f);
+        return true;
+    }
+    hipLaunchKernelGGL(dwconv17_kernel<false>, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16, (float*)nullptr, 0.f);
+    return false;
 }
 
 static void launch_dwconv17_bf16(const Ctx& c, const unsigned short* x, int ldx, const float* dw, unsigned short* y, int ldy, int C) {
@@ -236,13 +243,13 @@ static void launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned sho
 // bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
 // and the 8-step residual chain of h); statistics, gates and the outer residual stream x stay fp32.
 // x16: optional bf16 image of x (read by the two projections of x, rewritten with the block's result).
-static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C) {
+static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln) {
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);      // the gate exists as bf16 only
         a.bias = lw.b_gg; a.act = 2; a.A16 = x16; a.out16 = w.g16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
-    launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
+    if (!have_ln) launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
     {
         ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, nullptr, C);
         a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a; a.A16 = x16;
@@ -271,8 +278,9 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned 
     }
 }
 
-static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C) {
-    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, x16, lw, C); return; }
+// have_ln: w.rowstat already holds the LayerNorm statistics of x
+static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln = false) {
+    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, x16, lw, C, have_ln); return; }
     // g = sigmoid(x Wgg^T + b)
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
@@ -280,7 +288,7 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     // h = LayerNorm(x) Win^T + b   (normalisation folded into the epilogue)
-    launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
+    if (!have_ln) launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
     {
         ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, w.h0, C);
         a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in;
@@ -486,10 +494,11 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
             a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16;
             launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
         }
-        launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16);   // x += po + dwconv17(po)
+        // x += po + dwconv17(po), and the LayerNorm statistics of x that the gated TCN block starts with
+        const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, w.tc.rowstat);
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
         // ---- GatedTCNBlock ----
-        run_gated_tcn(c, w.tc, w.x, w.x16, lw, C);
+        run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln);
         if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);
     }
 

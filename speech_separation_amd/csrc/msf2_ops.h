@@ -156,14 +156,41 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const float* __restrict__ 
     }
 }
 
+// Sums of 16 per-lane values over the 64 lanes of a wave with 17 exchanges instead of 96: at each of the
+// first four levels a lane keeps one half of its values and hands the other half to its partner.  On
+// return a[0] of lane l is the wave total of value number rev4(l & 15) (bit-reversed low nibble).
+__device__ __forceinline__ int rev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
+__device__ __forceinline__ void rows16_sum(float (&a)[16], int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = 16 >> j, m = 1 << j;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int k = 0; k < n / 2; ++k) {
+            const float keep = up ? a[k + n / 2] : a[k];
+            const float send = up ? a[k] : a[k + n / 2];
+            a[k] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    a[0] += __shfl_xor(a[0], 16, 64);
+    a[0] += __shfl_xor(a[0], 32, 64);
+}
+
 // ---- ConvModule: y = x + dwconv17(x) along time (zero padded) ---------------
 // grid (ceil(C/4 / 128), ceil(S/TS), B), block 128, TS = 16.  dw: [17][C]; y16: optional bf16 copy of y
+// LN (needs C <= 512, i.e. one block per row tile): also writes the LayerNorm statistics (mean, rstd) of every
+// result row to ln_out[(b S + s) 2 ..], two-pass like rowstat_kernel<1>, from the values still in registers.
 constexpr int DW_TS = 16;
+template <bool LN>
 __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dw,
                                                        float* __restrict__ y, int ldy, int S, int C, int accumulate,
-                                                       unsigned short* __restrict__ y16) {
-    const int cq = blockIdx.x * 128 + threadIdx.x;
-    if (cq >= (C >> 2)) return;
+                                                       unsigned short* __restrict__ y16, float* __restrict__ ln_out, float ln_eps) {
+    __shared__ float red[2][2][DW_TS];
+    const int nq = C >> 2;
+    const int cq_raw = blockIdx.x * 128 + threadIdx.x;
+    if (!LN && cq_raw >= nq) return;
+    const bool act = cq_raw < nq;            // LN: idle lanes stay for the block reductions, reading a valid column
+    const int cq = act ? cq_raw : nq - 1;
     const int b = blockIdx.z, s0 = blockIdx.y * DW_TS;
     float4 w[17];
 #pragma unroll
@@ -194,12 +221,12 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 0; o < DW_TS; ++o) {
         const int s = s0 + o;
-        if (s < S) {
-            float4 v = acc[o];
-            if (accumulate) {
-                const float4 p = *reinterpret_cast<const float4*>(yb + (long)s * ldy);
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
+        if (accumulate) {      // (uniform) previous value of the row, from the clamped row like the inputs
+            const float4 p = *reinterpret_cast<const float4*>(yb + (long)min(s, S - 1) * ldy);
+            acc[o].x += p.x; acc[o].y += p.y; acc[o].z += p.z; acc[o].w += p.w;
+        }
+        if (s < S && act) {
+            const float4 v = acc[o];
             *reinterpret_cast<float4*>(yb + (long)s * ldy) = v;
             if (y16) {   // bf16 image of the result (pitch ldy) for the contractions that read it next
                 uint2 h;
@@ -207,6 +234,31 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
                 h.y = pk_bf16_pair(v.z, v.w);
                 *reinterpret_cast<uint2*>(y16 + ((long)b * S + s) * ldy + 4 * cq) = h;
             }
+        }
+    }
+    if constexpr (LN) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const float on = act ? 1.f : 0.f, inv_c = 1.f / (float)C;
+        float t[DW_TS];
+#pragma unroll
+        for (int o = 0; o < DW_TS; ++o) t[o] = (acc[o].x + acc[o].y + acc[o].z + acc[o].w) * on;
+        rows16_sum(t, lane);
+        if (lane < 16) red[0][wave][rev4(lane)] = t[0];
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < DW_TS; ++o) {
+            const float mean = (red[0][0][o] + red[0][1][o]) * inv_c;
+            const float a0 = acc[o].x - mean, a1 = acc[o].y - mean, a2 = acc[o].z - mean, a3 = acc[o].w - mean;
+            t[o] = (a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3) * on;
+        }
+        rows16_sum(t, lane);
+        if (lane < 16) red[1][wave][rev4(lane)] = t[0];
+        __syncthreads();
+        if (threadIdx.x < DW_TS && s0 + (int)threadIdx.x < S) {
+            const int o = threadIdx.x;
+            float* dst = ln_out + ((long)b * S + s0 + o) * 2;
+            dst[0] = (red[0][0][o] + red[0][1][o]) * inv_c;
+            dst[1] = rsqrtf((red[1][0][o] + red[1][1][o]) * inv_c + ln_eps);
         }
     }
 }
