@@ -144,7 +144,7 @@ static void launch_dwconv17_bf16(const Ctx& c, const unsigned short* x, int ldx,
 
 // ---- FLASH attention core ---------------------------------------------------
 struct AttnWs {
-    float *q4, *P, *part, *kv;
+    float *q4, *P, *part, *kv, *sqp;     // sqp: [M][E/64] partial sums of o^2
     int nsplit, chunk, G;
 };
 static int attn_nsplit(int B, int S) {
@@ -164,11 +164,13 @@ static AttnWs attn_ws(Arena& ar, int B, int S, int E) {
     w.P = ar.take<float>((long)B * w.G * MSF2_GROUP * MSF2_GROUP);
     w.part = ar.take<float>((long)B * w.nsplit * MSF2_QK_DIM * 2 * E);
     w.kv = ar.take<float>((long)B * MSF2_QK_DIM * 2 * E);
+    w.sqp = ar.take<float>((long)B * S * (E / (BN / 2)));
     return w;
 }
+// o_rnorm: optional [M] ScaleNorm inverse norms of the output rows (from partial sums the output kernel writes)
 static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ldhu, const float* gamma,
                           const float* beta, const float* freqs, float* o, int E, unsigned short* o16 = nullptr,
-                          const unsigned short* hu16 = nullptr) {
+                          const unsigned short* hu16 = nullptr, float* o_rnorm = nullptr) {
     // hu16 (bf16 mode): the hidden tensor [v | u | qk] is read as bf16 from there instead of fp32 from hu
     const long M = c.M;
     if (hu16)
@@ -194,9 +196,12 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
     }
     {
         AttnOutArgs a = {w.P, lin_q, hsrc, ldhu, w.kv, o, c.S, w.G, E, o16,
-                         reinterpret_cast<const unsigned short*>(w.P), reinterpret_cast<const unsigned short*>(lin_q)};
+                         reinterpret_cast<const unsigned short*>(w.P), reinterpret_cast<const unsigned short*>(lin_q),
+                         o_rnorm ? w.sqp : nullptr};
         if (hu16) launch_gemm<AttnOutT<true>>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
         else launch_gemm<AttnOut>(c, dim3(E / (BN / 2), 2, c.B * w.G), a);
+        if (o_rnorm)
+            hipLaunchKernelGGL(rowsq_finalize_kernel, dim3(cdiv(M, 256)), dim3(256), 0, c.st, w.sqp, E / (BN / 2), o_rnorm, M, c.S, E, 0);
     }
 }
 
@@ -483,12 +488,8 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         if (w.hu16) launch_dwconv17_bf16(c, w.hu_pre16, NH, lw.dw_hq, w.hu16, NH, NH);
         else launch_dwconv17(c, w.hu_pre, NH, lw.dw_hq, w.hu, NH, NH, 0);
         // bf16 mode: the attention output exists only as the bf16 image its projection reads
-        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o16 ? nullptr : w.o, E, w.o16, w.hu16);
-        if (w.o16)
-            hipLaunchKernelGGL((rowstat_kernel<0, true>), dim3(cdiv(c.M, 4)), dim3(256), 0, c.st,
-                               reinterpret_cast<const float*>(w.o16), E, w.rowstat, c.M, c.S, E, 0, 0.f);
-        else
-            launch_rowstat<0>(c, w.o, E, w.rowstat, E, 0, 0.f);
+        // (the ScaleNorm inverse norms of o come out of the attention's own output kernel)
+        run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o16 ? nullptr : w.o, E, w.o16, w.hu16, w.rowstat);
         {   // to_out projection
             ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);
             a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16;

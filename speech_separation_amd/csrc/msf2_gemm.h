@@ -922,6 +922,7 @@ struct AttnOutArgs {
     unsigned short* o16;             // optional bf16 copy of o
     const unsigned short* P16;       // HU16: bf16 scores [B*G][256][256] and bf16 lin_q [B*S][128], read instead of P / lq
     const unsigned short* lq16;
+    float* sq_part;                  // optional [B*S][E/64]: sum of o^2 over the 64 columns of each column tile (ScaleNorm of o)
 };
 template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
 struct AttnOutT {
@@ -1014,6 +1015,7 @@ struct AttnOutT {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         };
+        float ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tn = 0; tn < TN / 2; ++tn) {
             float4 av[4], au[4];
@@ -1027,10 +1029,22 @@ struct AttnOutT {
                 r.y = (au[i].y * v[tn][i].y) * sigmoid_f(av[i].y * u[tn][i].y);
                 r.z = (au[i].z * v[tn][i].z) * sigmoid_f(av[i].z * u[tn][i].z);
                 r.w = (au[i].w * v[tn][i].w) * sigmoid_f(av[i].w * u[tn][i].w);
+                ssq[i] += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
                 if (ok[i]) {
                     if (a.o) stg4_off(a.o, mrow[i] * e4 + j4, r);
                     if (a.o16) stg4_bf16_off(a.o16, (mrow[i] * e4 + j4) >> 1, r);
                 }
+            }
+        }
+        if (a.sq_part) {       // the 8 lanes that share a row add up their 64 columns
+            const unsigned np = a.E / (BN / 2), jt = j0 / (BN / 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = ssq[i];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                if (rc == 0 && ok[i]) a.sq_part[(long)mrow[i] * np + jt] = t;
             }
         }
     }

@@ -96,6 +96,20 @@ __global__ void posenc_kernel(const float* __restrict__ inv_freq, float scale, f
     pe[(long)s * C + half + j] = cosf(ang) * scale;
 }
 
+// ---- ScaleNorm inverse norm from partial sums of squares written by the producer of the rows ----------
+// part: [M][np]; out[m] = 1 / max(sqrt(sum) / sqrt(C), 1e-5).  shift: the first np / 2 partials (first half of
+// the features) are taken from the previous frame of the same utterance, none at frame 0 (token shift).
+__global__ void rowsq_finalize_kernel(const float* __restrict__ part, int np, float* __restrict__ out, long M, int S, int C, int shift) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float ss = 0.f;
+    const int h = shift ? np / 2 : 0;
+    for (int p = h; p < np; ++p) ss += part[m * np + p];
+    if (shift && m % S != 0)
+        for (int p = 0; p < h; ++p) ss += part[(m - 1) * np + p];
+    out[m] = 1.0f / fmaxf(sqrtf(ss) * rsqrtf((float)C), 1e-5f);
+}
+
 // ---- per-row statistics, one wave per row -----------------------------------
 // MODE 0: ScaleNorm inverse norm 1 / max(|x| / sqrt(C), 1e-5) of the
 //         (optionally token-shifted) row -> out[m]
