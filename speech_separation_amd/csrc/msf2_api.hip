@@ -59,8 +59,10 @@ static void launch_gemm(const Ctx& c, dim3 grid, const typename P::Args& a) {
 }
 
 // ---- projection launcher ----------------------------------------------------
+// Returns the width (columns) of the slabs over which the launched kernel writes partial row sums of squares to
+// a.sq_part ([M][ceil(N / width)]), or 0 when a.sq_part is null or the kernel chosen does not write them.
 template <int AMODE, int EPI>
-static void launch_proj(const Ctx& c, const ProjArgs& a) {
+static int launch_proj(const Ctx& c, const ProjArgs& a) {
     typedef ProjNT<AMODE, EPI> P;
     dim3 grid(cdiv(a.N, P::PAIRED ? BN / 2 : BN), cdiv(c.S, BM), c.B);
     // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
@@ -70,7 +72,7 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         !al(a.gmul, 15) || !al(a.bias, 15) || !al(a.bias2, 15) || !al(a.c1, 15) || !al(a.c2, 15) || !al(a.out16, 7) ||
         !al(a.res16, 7)) {
         g_bad_operand = true;
-        return;
+        return 0;
     }
     const TimedLaunch timed_(P::NSEG == 2 ? c.st : nullptr, P::NSEG == 2);
     // (the two-product form of the DMA kernel streams the bf16 residual with the operands, reads the column vector
@@ -94,7 +96,7 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
             if (want && (long)gb.x * gb.y * gb.z >= 1024) {
                 al.ncol_loop = 1;                 // 256 columns per tile already
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);
-                return;
+                return a.sq_part ? G::TN * 32 : 0;
             }
         }
         if (loop > (int)grid.x) loop = grid.x;
@@ -102,10 +104,12 @@ static void launch_proj(const Ctx& c, const ProjArgs& a) {
         al.ncol_loop = loop;
         grid.x = cdiv(grid.x, loop);
         hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 0>), grid, dim3(256), 0, c.st, al);
-    } else {
-        if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return; }     // only the DMA kernel reads the bf16 gate
-        launch_gemm<P>(c, grid, a);
+        return a.sq_part ? DmaGeom<P, 0>::TN * 32 : 0;
     }
+    if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return 0; }     // only the DMA kernel reads the bf16 gate
+    launch_gemm<P>(c, grid, a);
+    // the fp32 kernel finishes tiles with the row-major epilogue (64-column wave slabs); the register-staged bf16 one does not
+    return (a.sq_part && c.prec != MSF2_PREC_BF16) ? BN / P::WC : 0;
 }
 
 static ProjArgs proj_args(const float* A, int lda, const float* W, int K, int N, int S, float* out, int ldo) {
@@ -248,7 +252,9 @@ static void launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned sho
 // bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
 // and the 8-step residual chain of h); statistics, gates and the outer residual stream x stay fp32.
 // x16: optional bf16 image of x (read by the two projections of x, rewritten with the block's result).
-static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln) {
+// sq_part: optional [M][..] partial row sums of squares of the block's result (see launch_proj); returns their slab width
+static int run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln,
+                              float* sq_part) {
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);      // the gate exists as bf16 only
         a.bias = lw.b_gg; a.act = 2; a.A16 = x16; a.out16 = w.g16;
@@ -278,14 +284,15 @@ static void run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned 
     }
     {
         ProjArgs a = proj_args(nullptr, C, lw.w_po, C, C, c.S, x, C);
-        a.A16 = h16; a.bias = lw.b_po; a.res = x; a.ldr = C; a.out16 = x16;
-        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
+        a.A16 = h16; a.bias = lw.b_po; a.res = x; a.ldr = C; a.out16 = x16; a.sq_part = sq_part;
+        return launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
     }
 }
 
 // have_ln: w.rowstat already holds the LayerNorm statistics of x
-static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln = false) {
-    if (c.prec == MSF2_PREC_BF16) { run_gated_tcn_bf16(c, w, x, x16, lw, C, have_ln); return; }
+static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln = false,
+                         float* sq_part = nullptr) {
+    if (c.prec == MSF2_PREC_BF16) return run_gated_tcn_bf16(c, w, x, x16, lw, C, have_ln, sq_part);
     // g = sigmoid(x Wgg^T + b)
     {
         ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, w.g, C);
@@ -320,8 +327,8 @@ static void run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short
     // x += (g * h) Wpo^T + b
     {
         ProjArgs a = proj_args(h, C, lw.w_po, C, C, c.S, x, C);
-        a.bias = lw.b_po; a.res = x; a.ldr = C;
-        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
+        a.bias = lw.b_po; a.res = x; a.ldr = C; a.sq_part = sq_part;
+        return launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
     }
 }
 
@@ -336,7 +343,7 @@ static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, floa
 
 // ---- whole forward ----------------------------------------------------------
 struct FwdWs {
-    float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv, *zeros;
+    float *enc, *skip, *x, *hu_pre, *hu, *o, *po, *rowstat, *part, *bstat, *pe, *fv, *zeros, *sqx;
     unsigned short *x16, *o16;           // bf16 mode: operand images of the residual stream and the attention output
     unsigned short *hu_pre16, *hu16;     // bf16 mode: the hidden tensor before / after its ConvModule lives in bf16 only
     AttnWs at;
@@ -363,6 +370,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
     w.zeros = ar.take<float>(1024);      // >= K bytes: the DMA kernel's copy address of a zero row advances with k
+    w.sqx = ar.take<float>((long)B * S * cdiv(C, 64));   // partial row sums of squares of x, slabs of >= 64 columns
     w.x16 = w.o16 = w.hu_pre16 = w.hu16 = nullptr;
     if (cfg.precision == MSF2_PREC_BF16) {
         w.hu_pre16 = ar.take<unsigned short>(M * NH);
@@ -467,10 +475,13 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     hipLaunchKernelGGL(encoder_kernel, dim3(w.nblk_enc, B), dim3(256), 0, c.st, mix, wt->enc_w, w.enc, w.part, T, S, C, ENC_TS);
     launch_stats_finalize(c, w.part, w.nblk_enc, (long)S * C, 1e-8f, w.bstat);
     hipLaunchKernelGGL(posenc_kernel, dim3(cdiv((long)S * (C / 2), 256)), dim3(256), 0, c.st, wt->pe_inv_freq, wt->pe_scale, w.pe, S, C);
+    // Every producer of x also writes partial row sums of squares (slabs of sq_w columns) for the ScaleNorm of the
+    // token-shifted x that the next FLASH block starts with; sq_w == 0: the producer could not, a pass over x does it.
+    int sq_w = 0;
     {   // x = skip = GroupNorm(enc) Wce^T + pos_enc
         ProjArgs a = proj_args(w.enc, C, wt->w_ce, C, C, S, w.x, C);
-        a.out2 = w.skip; a.bstat = w.bstat; a.c1 = wt->c1_ce; a.c2 = wt->c2_ce; a.pe = w.pe; a.out16 = w.x16;
-        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+        a.out2 = w.skip; a.bstat = w.bstat; a.c1 = wt->c1_ce; a.c2 = wt->c2_ce; a.pe = w.pe; a.out16 = w.x16; a.sq_part = w.sqx;
+        sq_w = launch_proj<A_PLAIN, EPI_NORM>(c, a);
     }
     copy_tap(c, tp.enc, w.enc, MC);
     copy_tap(c, tp.x0, w.x, MC);
@@ -478,7 +489,10 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     for (int l = 0; l < cfg->num_layers; ++l) {
         const msf2_layer_weights& lw = wt->layers[l];
         // ---- FLASH_ShareA_FFConvM ----
-        launch_rowstat<0>(c, w.x, C, w.rowstat, C, 1, 0.f);
+        if (sq_w > 0 && (C / 2) % sq_w == 0)
+            hipLaunchKernelGGL(rowsq_finalize_kernel, dim3(cdiv(c.M, 256)), dim3(256), 0, c.st, w.sqx, cdiv(C, sq_w), w.rowstat, c.M, S, C, 1);
+        else
+            launch_rowstat<0>(c, w.x, C, w.rowstat, C, 1, 0.f);
         {   // [v | u | qk] = silu(ScaleNorm(shift(x)) W^T + b)
             ProjArgs a = proj_args(w.x, C, lw.w_hq, C, NH, S, w.hu_pre, NH);
             a.bias = lw.b_hq; a.rowstat = w.rowstat; a.act = 1; a.zeros = w.zeros; a.A16 = w.x16;
@@ -499,7 +513,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, w.tc.rowstat);
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
         // ---- GatedTCNBlock ----
-        run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln);
+        sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);
         if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);
     }
 

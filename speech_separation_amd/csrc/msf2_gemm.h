@@ -342,6 +342,7 @@ struct ProjArgs {
     const unsigned short* A16;  const unsigned short* A2_16;
     unsigned short* out16;
     const unsigned short* res16;   // residual read as bf16 instead of res (same pitch ldr)
+    float* sq_part;                // EPI_NORM / EPI_BIAS_RES, row-major epilogue: optional [M][ceil(N / w)] sums of out^2 over the w columns of a wave's slab
     int ncol_loop;                 // DMA kernel: consecutive column tiles one workgroup walks (0 = 1); grid.x shrinks accordingly
 };
 
@@ -570,6 +571,8 @@ struct ProjNT {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         };
+        constexpr bool SQ = (EPI == EPI_NORM || EPI == EPI_BIAS_RES);
+        float ssq[4] = {0.f, 0.f, 0.f, 0.f};
         load_tile(0);
 #pragma unroll
         for (int idx = 0; idx < NT; ++idx) {
@@ -627,6 +630,25 @@ struct ProjNT {
             const int n = n0 + wc * (TN * 32) + tn * 32 + 4 * rc;
             const bool nok = n < a.N;
             const unsigned nc4 = 4u * min(n, a.N - 4);
+            if (SQ && a.sq_part) {       // (uniform) partial row sums of squares over this wave's TN * 32 columns
+                const float keep = nok ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (tn == 0) ssq[i] = 0.f;
+                    ssq[i] += keep * (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
+                }
+                if (tn == TNE - 1) {
+                    const unsigned sw = TN * 32, np = (a.N + sw - 1) / sw, slab = (n0 + wc * sw) / sw;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t = ssq[i];
+                        t += __shfl_xor(t, 1, 64);
+                        t += __shfl_xor(t, 2, 64);
+                        t += __shfl_xor(t, 4, 64);
+                        if (rc == 0 && ok[i] && slab < np) a.sq_part[(long)mrow[i] * np + slab] = t;
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (idx == 0) after_first();
             if (idx + 1 < NT) load_tile(idx + 1);
