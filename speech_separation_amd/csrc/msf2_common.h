@@ -42,8 +42,10 @@ struct Arena {
     bool ok() const { return off <= cap; }
 };
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each) instead of an IEEE division: the quotient sequence costs ~10 instructions per
+// element, which is most of an epilogue's arithmetic.  exp(-x) = inf gives rcp(inf) = 0.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // two floats -> packed bf16 pair (low half = a), round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned pk_bf16_pair(float a, float b) {

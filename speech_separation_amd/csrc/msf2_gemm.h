@@ -613,7 +613,11 @@ struct ProjNT {
                     } else if constexpr (EPI == EPI_TANH_SIG) {
                         ve[e] = tanhf(x + be) * sigmoid_f(y + f4get(bias2v[tn], e));
                     } else {  // EPI_TCN
+#ifdef MSF2_DIAG_EPI_NOMATH
+                        ve[e] = rve + (x + be) * (y + f4get(c1v[tn], e));
+#else
                         ve[e] = (rve + sigmoid_f(x + be) * (rstd_b * y + f4get(c1v[tn], e))) * gve;   // c1 holds the folded statistics
+#endif
                     }
                 }
                 if constexpr (RESLDS) {        // bf16 output only (the DMA kernel's two-product form): packed at once
@@ -658,6 +662,9 @@ struct ProjNT {
                 if (ok[i] && nok) {
                     const unsigned off = mrow[i] * ldo4 + nc4;
                     if constexpr (RESLDS) {
+#ifdef MSF2_DIAG_EPI_NOSTORE
+                        if (vp[i].x == 0x12345678u)
+#endif
                         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out16) + (off >> 1)) = vp[i];
                         continue;
                     }
