@@ -235,13 +235,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     const int nrep = MULTI ? prob.col_tiles_here(G::NWX) : 1;
     const int total = nrep * nstream;
     P pf = prob;                 // the prefetch position runs NST tiles ahead of the consumer
-    int pf_t = 0, issued = 0;
+    int pf_t = 0, issued = 0, plain_left = 0;
     // Source addresses of this wave's copies at the prefetch position.  They advance by one k tile (64 B) per
     // issue and are derived from the problem only where the source is not linear in k: at the first k tile of
     // a product, and where the token-shifted half of the features ends.
     const unsigned short* pa[PA];
     const unsigned short* pb[PB];
-    auto derive = [&](int seg, int kt) {
+    auto derive = [&](int seg, int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int row = (wave * PA + i) * 16 + (lane >> 2);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
             pb[i] = pf.ptrB16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
         }
     };
-    auto issue = [&]() {
+    auto issue = [&]() __attribute__((always_inline)) {
         char* base = sm + (issued & (NST - 1)) * STAGE;
         if (RESLDS && pf_t >= nkt) {
             // residual rows 64 r .. 64 r + 63: one copy = 4 rows x 256 B, chunk swizzled on the source side
@@ -288,10 +288,43 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         }
         ++issued;
         if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }
+        // tiles from here on that need none of the above: same product, same source rows, the next 64 bytes
+        int q = nkt;
+        if (P::NSEG == 2 && pf_t <= nk0) q = nk0;
+        if (P::A_MODE == A_SHIFT && 2 * pf_t <= nk0) q = nk0 >> 1;
+        plain_left = (pf_t == 0) ? 0 : max(0, min(q - pf_t, total - issued));
+    };
+    // The common refill: one comparison, then the copies and their address increments.  Everything data dependent
+    // (product switch, residual tiles, next column tile, end of the stream) is in issue(), off the straight path.
+    auto refill = [&]() __attribute__((always_inline)) {
+        if (__builtin_expect(plain_left > 0, 1)) {
+            --plain_left;
+            char* base = sm + (issued & (NST - 1)) * STAGE;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_A)
+                if (pa[i] == nullptr)
+#endif
+                dma16(pa[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024)));
+                pa[i] += BK;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_B)
+                if (pb[i] == nullptr)
+#endif
+                dma16(pb[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024)));
+                pb[i] += BK;
+            }
+            ++issued;
+            if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }     // (the last k tile of a column tile without residual tiles)
+        } else if (issued < total) {
+            issue();
+        }
     };
     // Tile `idx` has landed once at most the copies of the tiles issued after it are outstanding.  Loads,
     // stores and copies retire in issue order, so epilogue stores issued in between only make this stricter.
-    auto wait_tile = [&](int idx) {
+    auto wait_tile = [&](int idx) __attribute__((always_inline)) {
         const int after = issued - idx - 1;
         if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
@@ -332,6 +365,14 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         for (int q = 0; q < TN; ++q) fb[q] = bf_frag(sb, rowB + q * 32, st, kh);
     };
     auto mfma_half = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN], f32x16 (&ac)[TM][TN]) {
+#ifdef MSF2_DIAG_NOMFMA
+        // timing-only build: the fragments are consumed by one cheap VALU instruction each instead of the MFMAs
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) ac[tm][0][0] += __builtin_bit_cast(float4, fa[tm]).x;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) ac[0][tn][1] += __builtin_bit_cast(float4, fb[tn]).x;
+        return;
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -340,20 +381,31 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
                                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tm], fb[tn], ac[tm][tn], 0, 0, 0);
     };
     auto step = [&](f32x16 (&ac)[TM][TN], bool last) {
+#ifdef MSF2_DIAG_HALFREADS
+#pragma unroll
+        for (int q = 0; q < TM; ++q) fa1[q] = fa0[q];       // timing-only build: half of the fragment reads never happen
+#pragma unroll
+        for (int q = 0; q < TN; ++q) fb1[q] = fb0[q];
+#else
         read_half(1, fa1, fb1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(fa0, fb0, ac);
         __builtin_amdgcn_sched_barrier(0);
         MSF2_STAMP(q0)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ++cons;
-        if (!last) wait_tile(cons);
+        // Second-half fragments are in registers (lgkmcnt) and tile `cons` has landed (vmcnt): while the stream is still
+        // being refilled exactly two younger tiles are behind it (three right after a column tile's residual tiles: then
+        // this is one tile stricter than needed); once nothing is left to issue, everything is awaited.
+        if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (__builtin_expect(issued < total, 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         MSF2_STAMP(q1)
         __builtin_amdgcn_s_barrier();
         MSF2_STAMP(q2)
         if (!last) read_half(0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (issued < total) issue();                    // into the slot of the tile this step consumed
+        refill();                                       // into the slot of the tile this step consumed
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(fa1, fb1, ac);
         __builtin_amdgcn_sched_barrier(0);
@@ -412,7 +464,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         // when it ends: by then they have long arrived, and nothing waits on them behind the copies in flight.
         CV cvn;
         const bool more = MULTI && rep + 1 < nrep;
-        auto next_vecs = [&]() { if (more) prob.template load_colvecs<TN, FOLDED>(prob.n0 + G::NWX, wc, lane, cvn); };
+        auto next_vecs = [&]() __attribute__((always_inline)) { if (more) prob.template load_colvecs<TN, FOLDED>(prob.n0 + G::NWX, wc, lane, cvn); };
         if constexpr (RESLDS) {
             // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
             wait_tile(cons + 1);
