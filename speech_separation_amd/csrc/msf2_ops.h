@@ -284,7 +284,7 @@ __device__ __forceinline__ float4 bf16x4_ld(const unsigned short* p) {
     return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
                        __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
 }
-__global__ __launch_bounds__(128) void dwconv17_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
+__global__ __launch_bounds__(128, 3) void dwconv17_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
                                                             const float* __restrict__ dw, unsigned short* __restrict__ y,
                                                             int ldy, int S, int C) {
     const int cq = blockIdx.x * 128 + threadIdx.x;
