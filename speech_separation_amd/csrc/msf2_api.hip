@@ -196,7 +196,8 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
     {
         // bf16 mode: scores and lin_q exist as bf16 only (the values the contraction would round them to anyway)
         SimArgs a = {quad_q, quad_k, w.P, c.S, w.G, hu16 ? reinterpret_cast<unsigned short*>(w.P) : nullptr};
-        launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
+        if (hu16) launch_gemm<AttnSimT<true>>(c, dim3(2, 2, c.B * w.G), a);
+        else launch_gemm<AttnSim>(c, dim3(2, 2, c.B * w.G), a);
     }
     {
         AttnOutArgs a = {w.P, lin_q, hsrc, ldhu, w.kv, o, c.S, w.G, E, o16,

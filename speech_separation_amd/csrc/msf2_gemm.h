@@ -837,10 +837,11 @@ struct SimArgs {
     int S, G;
     unsigned short* P16;               // when set, the scores are written as bf16 here instead of fp32 to P
 };
-struct AttnSim {
+template <bool IN16>       // IN16: a.q / a.k point at bf16 values (same indexing), read as they are by the bf16 kernel
+struct AttnSimT {
     typedef SimArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, NACC = 1, A_ORI = ORI_KC, B_ORI = ORI_KC;
-    static constexpr bool A_BF16 = false, B_BF16 = false;
+    static constexpr bool A_BF16 = IN16, B_BF16 = IN16;
     static constexpr bool ACC_T = false, EPI_RM = false;
     Args a;
     int b, g, m0, n0;
@@ -856,6 +857,12 @@ struct AttnSim {
     }
     __device__ const float* ptrA(int, int kt, int r, int ko) const { return row(a.q, m0 + r, kt * BK + ko); }
     __device__ const float* ptrB(int, int kt, int c, int ko) const { return row(a.k, n0 + c, kt * BK + ko); }
+    __device__ const unsigned short* row16(const float* p, int i, int k) const {
+        const int s = min(g * MSF2_GROUP + i, a.S - 1);
+        return reinterpret_cast<const unsigned short*>(p) + ((long)b * a.S + s) * MSF2_QK_DIM + k;
+    }
+    __device__ const unsigned short* ptrA16(int, int kt, int r, int ko) const { return row16(a.q, m0 + r, kt * BK + ko); }
+    __device__ const unsigned short* ptrB16(int, int kt, int c, int ko) const { return row16(a.k, n0 + c, kt * BK + ko); }
     template <int TM, int TN>
     __device__ void epilogue(f32x16 (&acc)[1][TM][TN], int wr, int wc, int lane, float*) const {
         float* P = a.P + (long)blockIdx.z * MSF2_GROUP * MSF2_GROUP;
@@ -874,6 +881,8 @@ struct AttnSim {
     }
 };
 
+typedef AttnSimT<false> AttnSim;
+
 // ---------------------------------------------------------------------------
 // Linear-attention key/value summary, split over time:
 //   part[b, sp, d, e] = sum_{s in chunk sp} lin_k[b, s, d] * hu[b, s, e]
@@ -886,7 +895,7 @@ struct LinKVArgs {
     float* part;                     // [B][nsplit][128][N]
     int S, N, chunk;
 };
-template <bool HU16>       // HU16: a.hu points at bf16 values (same indexing)
+template <bool HU16>       // HU16: a.hu and a.lk point at bf16 values (same indexing)
 struct LinKVT {
     typedef LinKVArgs Args;
     static constexpr int WR = 2, WC = 2, NSEG = 1, NACC = 1, A_ORI = ORI_RC, B_ORI = ORI_RC;
@@ -907,7 +916,9 @@ struct LinKVT {
     __device__ float4 fetchA(int, int kt, int r, int ko) const {
         const int s = k0 + kt * BK + ko;
         const float m = s < k1 ? 1.f : 0.f;
-        return mul4(ld4(a.lk + ((long)b * a.S + min(s, k1 - 1)) * MSF2_QK_DIM + r), m);
+        const long off = ((long)b * a.S + min(s, k1 - 1)) * MSF2_QK_DIM + r;
+        if constexpr (HU16) return mul4(ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.lk) + off, 0u), m);   // lin_k is bf16 too
+        else return mul4(ld4(a.lk + off), m);
     }
     __device__ float4 fetchB(int, int kt, int c, int ko) const {
         const int s = k0 + kt * BK + ko;

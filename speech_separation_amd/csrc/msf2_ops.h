@@ -329,7 +329,8 @@ __global__ __launch_bounds__(128, 3) void dwconv17_bf16_kernel(const unsigned sh
 // ---- OffsetScale + rotary -> quad_q/256, lin_q, quad_k, lin_k ----------------
 // qk: [M] rows, row stride ld (already offset to the qk columns).  q4: [4][M][128].
 // grid ceil(M/4), block 256 (64 lanes = 64 feature pairs of one row)
-// IN16 (bf16 mode): qk points at bf16 values (same indexing) and lin_q is written as bf16.
+// IN16 (bf16 mode): qk points at bf16 values (same indexing) and the outputs are written as bf16
+// (slot h of q4 then holds [M][128] bf16 in its first half).
 template <bool IN16>
 __global__ __launch_bounds__(256) void qk_prep_kernel(const void* __restrict__ qk_, int ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(const void* __restrict__ q
         o.x = y0 * c - y1 * sn;
         o.y = y1 * c + y0 * sn;
         if (h == 0) { o.x *= (1.0f / MSF2_GROUP); o.y *= (1.0f / MSF2_GROUP); }
-        if (IN16 && h == 1)      // bf16 mode: lin_q is only ever a bf16 contraction operand; its slot holds [M][128] bf16
-            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(q4 + (long)M * MSF2_QK_DIM) + m * MSF2_QK_DIM + 2 * p) = pk_bf16_pair(o.x, o.y);
+        if (IN16)      // bf16 mode: the four outputs are only ever bf16 contraction operands; each slot holds [M][128] bf16
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(q4 + (long)h * M * MSF2_QK_DIM) + m * MSF2_QK_DIM + 2 * p) = pk_bf16_pair(o.x, o.y);
         else
             *reinterpret_cast<float2*>(q4 + ((long)h * M + m) * MSF2_QK_DIM + 2 * p) = o;
     }
