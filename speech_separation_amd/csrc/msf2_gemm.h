@@ -56,6 +56,12 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
                  :: "v"(src), "s"(lds_base) : "memory", "m0");
 }
 
+// the same copy with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16_so(const void* base, unsigned byte_off, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(byte_off), "s"(base), "s"(lds_base) : "memory", "m0");
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 mul4(float4 v, float m) { v.x *= m; v.y *= m; v.z *= m; v.w *= m; return v; }
 __device__ __forceinline__ float f4get(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
@@ -423,6 +429,21 @@ struct ProjNT {
             return (sh && s == 0) ? reinterpret_cast<const unsigned short*>(a.zeros) : p;
         }
         return base + row * a.lda + k;
+    }
+    // The same two addresses split into a wave-uniform base and a per-lane byte offset (plain A operand, unpaired
+    // columns): the base advances with k, the offsets of a wave's copies stay fixed for a whole product.
+    __device__ const unsigned short* baseA16(int seg, int kt) const {
+        const unsigned short* base = (NSEG == 2 && seg == 1) ? a.A2_16 : a.A16;
+        return base + ((long)b * a.S + s0) * a.lda + kt * BK;
+    }
+    __device__ unsigned offA16(int r, int ko) const {
+        return (unsigned)(((min(s0 + r, a.S - 1) - s0) * a.lda + ko) * 2);
+    }
+    __device__ const unsigned short* baseB16(int seg, int kt) const {
+        return reinterpret_cast<const unsigned short*>((NSEG == 2 && seg == 1) ? a.W2 : a.W) + kt * BK;
+    }
+    __device__ unsigned offB16(int c, int ko) const {
+        return (unsigned)((min(n0 + c, a.N - 1) * a.K + ko) * 2);
     }
     // bf16 residual (a.res16, pitch ldr) of row r of this workgroup's tile, 8 columns from column n0 + c
     __device__ const unsigned short* ptrRes16(int r, int c) const {

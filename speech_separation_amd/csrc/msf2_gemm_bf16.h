@@ -240,19 +240,58 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     // Source addresses of this wave's copies at the prefetch position.  They advance by one k tile (64 B) per
     // issue and are derived from the problem only where the source is not linear in k: at the first k tile of
     // a product, and where the token-shifted half of the features ends.
+    // SADDR (plain A operand, unpaired columns): wave-uniform bases in SGPRs + fixed 32-bit lane offsets instead.
+    constexpr bool SADDR = (P::A_MODE == A_PLAIN) && !P::PAIRED;
     const unsigned short* pa[PA];
     const unsigned short* pb[PB];
+    unsigned oa[PA], ob[PB];
+    const unsigned short* ba = nullptr;
+    const unsigned short* bb = nullptr;
     auto derive = [&](int seg, int kt) __attribute__((always_inline)) {
+        if constexpr (SADDR) {
+            ba = pf.baseA16(seg, kt);
+            bb = pf.baseB16(seg, kt);
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int row = (wave * PA + i) * 16 + (lane >> 2);
-            pa[i] = pf.ptrA16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+            if constexpr (SADDR) oa[i] = pf.offA16(row, ((lane & 3) ^ bf_swz(row)) * 8);
+            else pa[i] = pf.ptrA16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int row = (wave * PB + i) * 16 + (lane >> 2);
-            pb[i] = pf.ptrB16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+            if constexpr (SADDR) ob[i] = pf.offB16(row, ((lane & 3) ^ bf_swz(row)) * 8);
+            else pb[i] = pf.ptrB16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
         }
+    };
+    // the copies of one k tile into ring slot `base`, then one k tile further
+    auto copy_tile = [&](char* base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024));
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_A)
+            if (base == nullptr)      // timing-only builds: address arithmetic kept, copy never issued
+#endif
+            {
+                if constexpr (SADDR) dma16_so(ba, oa[i], lds);
+                else dma16(pa[i], lds);
+            }
+            if constexpr (!SADDR) pa[i] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024));
+#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_B)
+            if (base == nullptr)
+#endif
+            {
+                if constexpr (SADDR) dma16_so(bb, ob[i], lds);
+                else dma16(pb[i], lds);
+            }
+            if constexpr (!SADDR) pb[i] += BK;
+        }
+        if constexpr (SADDR) { ba += BK; bb += BK; }
     };
     auto issue = [&]() __attribute__((always_inline)) {
         char* base = sm + (issued & (NST - 1)) * STAGE;
@@ -270,22 +309,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
             const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
             const int kt = pf_t - seg * nk0;
             if (kt == 0 || (P::A_MODE == A_SHIFT && 2 * kt == nk0)) derive(seg, kt);
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_A)
-                if (pa[i] == nullptr)     // timing-only builds: address arithmetic kept, copy never issued
-#endif
-                dma16(pa[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024)));
-                pa[i] += BK;
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_B)
-                if (pb[i] == nullptr)
-#endif
-                dma16(pb[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024)));
-                pb[i] += BK;
-            }
+            copy_tile(base);
         }
         ++issued;
         if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }
@@ -300,23 +324,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     auto refill = [&]() __attribute__((always_inline)) {
         if (__builtin_expect(plain_left > 0, 1)) {
             --plain_left;
-            char* base = sm + (issued & (NST - 1)) * STAGE;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_A)
-                if (pa[i] == nullptr)
-#endif
-                dma16(pa[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + (wave * PA + i) * 1024)));
-                pa[i] += BK;
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-#if defined(MSF2_DIAG_NODMA) || defined(MSF2_DIAG_NODMA_B)
-                if (pb[i] == nullptr)
-#endif
-                dma16(pb[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + TILE_A + (wave * PB + i) * 1024)));
-                pb[i] += BK;
-            }
+            copy_tile(sm + (issued & (NST - 1)) * STAGE);
             ++issued;
             if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }     // (the last k tile of a column tile without residual tiles)
         } else if (issued < total) {
