@@ -311,9 +311,16 @@ static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short*
     float* hn = w.h1;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        hipLaunchKernelGGL(tcn_stage_a_kernel, dim3(w.nblk, c.B), dim3(256), 0, c.st, h, (const unsigned short*)nullptr,
-                           tw.dw_w, tw.dw_b, w.t, (unsigned short*)nullptr, w.part,
-                           c.S, C, 1 << j, TCN_TS);
+        {
+            const dim3 grid(w.nblk, c.B), blk(256);
+            const int dil = 1 << j;
+            switch (C) {   // frames per thread = 32 / (256 / (C / 4))
+                case 512: hipLaunchKernelGGL(tcn_stage_a_kernel<16>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                case 256: hipLaunchKernelGGL(tcn_stage_a_kernel<8>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                case 128: hipLaunchKernelGGL(tcn_stage_a_kernel<4>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                default:  hipLaunchKernelGGL(tcn_stage_a_kernel<2>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+            }
+        }
         launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
         a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;

@@ -384,52 +384,50 @@ __global__ void kv_finalize_kernel(const float* __restrict__ part, float* __rest
 }
 
 // ---- TCN stage A: t = silu(dwconv3_dilated(h) + bias), + partial sums --------
-// t16 != nullptr: write t as bf16 there (the contraction that consumes it runs in bf16) instead of fp32 to t;
-// the statistics are always taken from the fp32 values.
-// h16 != nullptr: the input is read as bf16 from there instead of fp32 from h.
-__device__ __forceinline__ float4 bf16x4_to_f32(uint2 p) {
-    return make_float4(__builtin_bit_cast(float, p.x << 16), __builtin_bit_cast(float, p.x & 0xffff0000u),
-                       __builtin_bit_cast(float, p.y << 16), __builtin_bit_cast(float, p.y & 0xffff0000u));
-}
-__global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const unsigned short* __restrict__ h16,
-                                                          const float* __restrict__ w,
+// fp32 in / fp32 out: 4 channels (16 bytes) per lane, 32 frames per block; a thread's NIT frames are
+// handled 8 at a time with all 24 row loads of a group issued up front from clamped rows (taps outside
+// the utterance are zeroed by a 0/1 factor, never by a predicated load, which hipcc would wait on in place).
+// grid (ceil(S/32), B), block 256, NIT = 32 / (256 / (C/4)).
+template <int NIT>
+__global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ t,
-                                                          unsigned short* __restrict__ t16,
-                                                          float* __restrict__ part, int S, int C, int dil, int TS) {
+                                                          float* __restrict__ part, int S, int C, int dil) {
     __shared__ float red[8];
-    const QuadMap qm(C);
-    const int b = blockIdx.y, s0 = blockIdx.x * TS, s1 = min(s0 + TS, S);
-    const int c = 4 * qm.cq;
+    const int lpf = C >> 2, cq = threadIdx.x % lpf, fo = threadIdx.x / lpf, nf = 256 / lpf;
+    const int b = blockIdx.y, s0 = blockIdx.x * 32;
+    const int c = 4 * cq;
     const float4 w0 = *reinterpret_cast<const float4*>(w + c);
     const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
     const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
     const float4 bs = *reinterpret_cast<const float4*>(bias + c);
-    const long boff = (long)b * S * C + c;
+    const float* hb = h + (long)b * S * C + c;
     float sum = 0.f, sq = 0.f;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ldrow = [&](int s) -> float4 {
-        if (h16) return bf16x4_to_f32(*reinterpret_cast<const uint2*>(h16 + boff + (long)s * C));
-        return *reinterpret_cast<const float4*>(h + boff + (long)s * C);
-    };
-    for (int s = s0 + qm.fo; s < s1; s += qm.nf) {
-        const float4 xm = (s - dil >= 0) ? ldrow(s - dil) : z;
-        const float4 x0 = ldrow(s);
-        const float4 xp = (s + dil < S) ? ldrow(s + dil) : z;
-        float4 v;
-        v.x = silu_f(w0.x * xm.x + w1.x * x0.x + w2.x * xp.x + bs.x);
-        v.y = silu_f(w0.y * xm.y + w1.y * x0.y + w2.y * xp.y + bs.y);
-        v.z = silu_f(w0.z * xm.z + w1.z * x0.z + w2.z * xp.z + bs.z);
-        v.w = silu_f(w0.w * xm.w + w1.w * x0.w + w2.w * xp.w + bs.w);
-        if (t16) {
-            uint2 pk;
-            pk.x = pk_bf16_pair(v.x, v.y);
-            pk.y = pk_bf16_pair(v.z, v.w);
-            *reinterpret_cast<uint2*>(t16 + ((long)b * S + s) * C + c) = pk;
-        } else {
-            *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+    constexpr int UN = NIT < 8 ? NIT : 8;
+#pragma unroll
+    for (int i0 = 0; i0 < NIT; i0 += UN) {
+        float4 xm[UN], x0[UN], xp[UN];
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            const int s = min(s0 + fo + nf * (i0 + i), S - 1);
+            xm[i] = *reinterpret_cast<const float4*>(hb + (long)max(s - dil, 0) * C);
+            x0[i] = *reinterpret_cast<const float4*>(hb + (long)s * C);
+            xp[i] = *reinterpret_cast<const float4*>(hb + (long)min(s + dil, S - 1) * C);
         }
-        sum += v.x + v.y + v.z + v.w;
-        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            const int s = s0 + fo + nf * (i0 + i);
+            const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
+            float4 v;
+            v.x = silu_f(w0.x * (xm[i].x * fm) + w1.x * x0[i].x + w2.x * (xp[i].x * fp) + bs.x);
+            v.y = silu_f(w0.y * (xm[i].y * fm) + w1.y * x0[i].y + w2.y * (xp[i].y * fp) + bs.y);
+            v.z = silu_f(w0.z * (xm[i].z * fm) + w1.z * x0[i].z + w2.z * (xp[i].z * fp) + bs.z);
+            v.w = silu_f(w0.w * (xm[i].w * fm) + w1.w * x0[i].w + w2.w * (xp[i].w * fp) + bs.w);
+            if (s < S) {
+                *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+                sum += v.x + v.y + v.z + v.w;
+                sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
     }
     write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
 }
