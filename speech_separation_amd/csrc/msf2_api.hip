@@ -130,9 +130,16 @@ static void launch_rowstat(const Ctx& c, const float* x, int ldx, float* out, in
 
 // ln_out: optional [M][2] LayerNorm statistics (mean, rstd; eps 1e-5) of the result rows, written by the same kernel
 // when a row fits one block (C <= 512).  Returns whether they were written.
+// x16: the input is read as bf16 from there instead of fp32 from x (only together with ln_out and C <= 512).
 static bool launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* dw, float* y, int ldy, int C, int accumulate,
-                            unsigned short* y16 = nullptr, float* ln_out = nullptr) {
+                            unsigned short* y16 = nullptr, float* ln_out = nullptr, const unsigned short* x16 = nullptr) {
     dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
+    if (x16) {
+        if (!ln_out || grid.x != 1) { g_bad_operand = true; return false; }
+        hipLaunchKernelGGL((dwconv17_kernel<true, true>), grid, dim3(128), 0, c.st, reinterpret_cast<const float*>(x16), ldx, dw, y, ldy,
+                           c.S, C, accumulate, y16, ln_out, 1e-5f);
+        return true;
+    }
     if (ln_out && grid.x == 1) {
         hipLaunchKernelGGL(dwconv17_kernel<true>, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C, accumulate, y16, ln_out, 1e-5f);
         return true;
@@ -513,12 +520,15 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         // (the ScaleNorm inverse norms of o come out of the attention's own output kernel)
         run_attention(c, w.at, w.hu, NH, lw.os_gamma, lw.os_beta, lw.rot_freqs, w.o16 ? nullptr : w.o, E, w.o16, w.hu16, w.rowstat);
         {   // to_out projection
-            ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, w.po, C);
-            a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16;
+            // bf16 mode (C <= 512): po exists as bf16 only, in the first half of its buffer
+            unsigned short* po16 = (w.o16 && C <= 512) ? reinterpret_cast<unsigned short*>(w.po) : nullptr;
+            ProjArgs a = proj_args(w.o, E, lw.w_out, E, C, S, po16 ? nullptr : w.po, C);
+            a.bias = lw.b_out; a.rowstat = w.rowstat; a.act = 1; a.A16 = w.o16; a.out16 = po16;
             launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
         }
         // x += po + dwconv17(po), and the LayerNorm statistics of x that the gated TCN block starts with
-        const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, w.tc.rowstat);
+        const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, w.tc.rowstat,
+                                             (w.o16 && C <= 512) ? reinterpret_cast<const unsigned short*>(w.po) : nullptr);
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
         // ---- GatedTCNBlock ----
         sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);

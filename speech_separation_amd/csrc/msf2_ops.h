@@ -195,7 +195,8 @@ __device__ __forceinline__ void rows16_sum(float (&a)[16], int lane) {
 // LN (needs C <= 512, i.e. one block per row tile): also writes the LayerNorm statistics (mean, rstd) of every
 // result row to ln_out[(b S + s) 2 ..], two-pass like rowstat_kernel<1>, from the values still in registers.
 constexpr int DW_TS = 16;
-template <bool LN>
+// IN16: x points at bf16 values (same indexing, pitch ldx in elements).
+template <bool LN, bool IN16 = false>
 __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dw,
                                                        float* __restrict__ y, int ldy, int S, int C, int accumulate,
                                                        unsigned short* __restrict__ y16, float* __restrict__ ln_out, float ln_eps) {
@@ -213,13 +214,21 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 0; o < DW_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xb = x + (long)b * S * ldx + 4 * cq;
+    const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(x) + (long)b * S * ldx + 4 * cq;
 #pragma unroll
     for (int r = -8; r < DW_TS + 8; ++r) {
         const int s = s0 + r;
         // unconditional load from the clamped row, zeroed by a 0/1 factor: a predicated load makes
         // hipcc branch around it and wait for it on the spot, which serialises the 32 row loads
         const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
-        float4 xv = *reinterpret_cast<const float4*>(xb + (long)min(max(s, 0), S - 1) * ldx);
+        float4 xv;
+        if constexpr (IN16) {
+            const uint2 hq = *reinterpret_cast<const uint2*>(xb16 + (long)min(max(s, 0), S - 1) * ldx);
+            xv = make_float4(__builtin_bit_cast(float, hq.x << 16), __builtin_bit_cast(float, hq.x & 0xffff0000u),
+                             __builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u));
+        } else {
+            xv = *reinterpret_cast<const float4*>(xb + (long)min(max(s, 0), S - 1) * ldx);
+        }
         xv.x *= inb; xv.y *= inb; xv.z *= inb; xv.w *= inb;
 #pragma unroll
         for (int o = 0; o < DW_TS; ++o) {
