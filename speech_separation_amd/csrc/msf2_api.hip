@@ -91,8 +91,19 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             dim3 gb(cdiv(a.N, G::BNX), cdiv(c.S, G::BMX), c.B);
             // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 5 % for the N = 2176 one
             // (its ninth 256-column tile half empty); the two-product TCN contraction keeps the 128 x 128 form
-            static const int big_maxn = getenv("MSF2_BIG_MAXN") ? atoi(getenv("MSF2_BIG_MAXN")) : 4096;
+            const int big_maxn = getenv("MSF2_BIG_MAXN") ? atoi(getenv("MSF2_BIG_MAXN")) : 4096;
             const bool want = a.N <= big_maxn && getenv("MSF2_NO_BIG") == nullptr;
+            // 128 x 256 tiles, two workgroups per CU, where the epilogue weighs most (residual read + two writes; the
+            // widest output): measured 6 % / 2 % faster than the 256 x 256 form there, equal elsewhere
+            const int geom2_env = getenv("MSF2_GEOM2") ? atoi(getenv("MSF2_GEOM2")) : -1;
+            const bool geom2 = geom2_env >= 0 ? geom2_env != 0 : (EPI == EPI_BIAS_RES || a.N > 1024);
+            if (want && geom2 && (long)cdiv(a.N, 256) * cdiv(c.S, 128) * c.B >= 1024) {
+                typedef DmaGeom<P, 2> G2;
+                dim3 g2(cdiv(a.N, G2::BNX), cdiv(c.S, G2::BMX), c.B);
+                al.ncol_loop = 1;
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 2>), g2, dim3(G2::THREADS), 0, c.st, al);
+                return a.sq_part ? G2::TN * 32 : 0;
+            }
             if (want && (long)gb.x * gb.y * gb.z >= 1024) {
                 al.ncol_loop = 1;                 // 256 columns per tile already
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);

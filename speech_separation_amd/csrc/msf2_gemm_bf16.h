@@ -202,8 +202,17 @@ template <class P> struct DmaGeom<P, 1> {
     static constexpr int BMX = 256, BNX = WC * TN * 32, NWX = BNX, NST = 4, MINB = 1;
 };
 
+//   BIG = 2: 128 x 256 tile, 4 waves as 2 x 2 (64 x 128 per wave), 3-slot ring (72 KB, the epilogue tiles reuse slot 0 once
+//            the stream has ended), TWO workgroups per CU: 0.75x the copy bytes per MFMA of BIG = 0, and unlike
+//            BIG = 1 the epilogue of one workgroup (half of the time of a K = 512 projection) runs under the K loop
+//            of the other.
+template <class P> struct DmaGeom<P, 2> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 4;
+    static constexpr int BMX = 128, BNX = 256, NWX = 256, NST = 3, MINB = 2;
+};
+
 template <class P, int BIG>
-__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
+__global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
     static_assert(BIG == 0 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
@@ -211,7 +220,9 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     constexpr int PA = G::BMX / 16 / NWAVES, PB = G::BNX / 16 / NWAVES;                  // copies per wave and k tile: 16 rows x 64 B each
     constexpr int DMA_PER_TILE = PA + PB;
     static_assert(PA >= 1 && PB >= 1 && PA * 16 * NWAVES == G::BMX && PB * 16 * NWAVES == G::BNX, "tile rows must split evenly over the waves");
-    __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + NWAVES * 4096];      // ring + one 4 KiB epilogue tile per wave
+    constexpr bool STAGE_IN_RING = (BIG == 2);    // the epilogue tiles lie over slot 0 (no copy is in flight by then)
+    static_assert(!STAGE_IN_RING || NWAVES * 4096 <= STAGE, "the epilogue tiles must fit one ring slot");
+    __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + (STAGE_IN_RING ? 0 : NWAVES * 4096)];   // ring (+ one 4 KiB epilogue tile per wave)
     P prob;
     if constexpr (BIG) prob.init_tile(args, G::BMX, G::NWX);
     else prob.init(args);
@@ -235,6 +246,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     constexpr bool MULTI = (BIG == 0);
     const int nrep = MULTI ? prob.col_tiles_here(G::NWX) : 1;
     const int total = nrep * nstream;
+    // ring slot of stream tile i (NST is 4 or 3)
+    auto slot = [&](int i) __attribute__((always_inline)) { return (NST & (NST - 1)) == 0 ? (i & (NST - 1)) : (int)((unsigned)i % (unsigned)NST); };
     P pf = prob;                 // the prefetch position runs NST tiles ahead of the consumer
     int pf_t = 0, issued = 0, plain_left = 0;
     // Source addresses of this wave's copies at the prefetch position.  They advance by one k tile (64 B) per
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         if constexpr (SADDR) { ba += BK; bb += BK; }
     };
     auto issue = [&]() __attribute__((always_inline)) {
-        char* base = sm + (issued & (NST - 1)) * STAGE;
+        char* base = sm + slot(issued) * STAGE;
         if (RESLDS && pf_t >= nkt) {
             // residual rows 64 r .. 64 r + 63: one copy = 4 rows x 256 B, chunk swizzled on the source side
             const int r = pf_t - nkt;
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     auto refill = [&]() __attribute__((always_inline)) {
         if (__builtin_expect(plain_left > 0, 1)) {
             --plain_left;
-            copy_tile(sm + (issued & (NST - 1)) * STAGE);
+            copy_tile(sm + slot(issued) * STAGE);
             ++issued;
             if (++pf_t == nstream) { pf_t = 0; pf.n0 += G::NWX; }     // (the last k tile of a column tile without residual tiles)
         } else if (issued < total) {
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     // column tile does not read ahead (the stream continues with residual tiles or after the epilogue).
     bf16x8_t fa0[TM] = {}, fb0[TN] = {}, fa1[TM] = {}, fb1[TN] = {};
     auto read_half = [&](int st, bf16x8_t (&fa)[TM], bf16x8_t (&fb)[TN]) {
-        const char* sa = sm + (cons & (NST - 1)) * STAGE;
+        const char* sa = sm + slot(cons) * STAGE;
         const char* sb = sa + TILE_A;
 #ifdef MSF2_DIAG_NOREADS
         if (sa != nullptr) return;      // timing-only build: no fragment reads at all
@@ -407,10 +420,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
         MSF2_STAMP(q0)
         ++cons;
         // Second-half fragments are in registers (lgkmcnt) and tile `cons` has landed (vmcnt): while the stream is still
-        // being refilled exactly two younger tiles are behind it (three right after a column tile's residual tiles: then
+        // being refilled exactly NST - 2 younger tiles are behind it (three right after a column tile's residual tiles: then
         // this is one tile stricter than needed); once nothing is left to issue, everything is awaited.
         if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if (__builtin_expect(issued < total, 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+        else if (__builtin_expect(issued < total, 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((NST - 2) * DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         MSF2_STAMP(q1)
 #ifndef MSF2_DIAG_NOBARRIER
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm_kernel_bf16
     unsigned long long e0 = 0, e1 = 0, e2 = 0, l0 = 0;
     MSF2_STAMP(e0)
 #endif
-    float* stage = reinterpret_cast<float*>(sm + NST * STAGE) + wave * 1024;
+    float* stage = reinterpret_cast<float*>(sm + (STAGE_IN_RING ? 0 : NST * STAGE)) + wave * 1024;
     for (int rep = 0; rep < nrep; ++rep) {
         f32x16 acc[P::NSEG][TM][TN];
 #pragma unroll

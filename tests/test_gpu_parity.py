@@ -303,7 +303,7 @@ def test_bf16_full_model_si_sdr(golden_dir):
 
 def test_bf16_kernel_choices_agree():
     """The bf16 projections pick their kernel by problem size (register-staged, 128 x 128 global->LDS ring with
-    1 or 2 column tiles per workgroup, 256-row 8-wave geometry).  Every choice performs the same arithmetic
+    1 or 2 column tiles per workgroup, 256 x 256 8-wave geometry, 128 x 256 geometry).  Every choice performs the same arithmetic
     in the same order per output element, so a gated TCN block at a size that enables all of them must
     not depend on which one ran."""
     g = torch.Generator().manual_seed(21)
@@ -314,8 +314,9 @@ def test_bf16_kernel_choices_agree():
     x = torch.randn(B, S, C, generator=g).to(DEV)
     outs = {}
     for name, env in (("default", {}), ("no_big", {"MSF2_NO_BIG": "1"}), ("loop1", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "1"}),
-                      ("loop4", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "4"})):
-        for k in ("MSF2_NO_BIG", "MSF2_NCOL_LOOP"):
+                      ("loop4", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "4"}),
+                      ("geom2_all", {"MSF2_GEOM2": "1"}), ("geom2_none", {"MSF2_GEOM2": "0"})):
+        for k in ("MSF2_NO_BIG", "MSF2_NCOL_LOOP", "MSF2_GEOM2"):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -324,7 +325,7 @@ def test_bf16_kernel_choices_agree():
             for k in env:
                 os.environ.pop(k, None)
     assert torch.isfinite(outs["default"]).all()
-    for name in ("no_big", "loop1", "loop4"):
+    for name in ("no_big", "loop1", "loop4", "geom2_all", "geom2_none"):
         assert torch.equal(outs[name], outs["default"]), name
 
 
