@@ -578,6 +578,10 @@ struct ProjNT {
             }
         };
         auto transpose = [&](const f32x16& t, float4 (&o)[4]) {
+#ifdef MSF2_DIAG_EPI_NOTRANSPOSE
+            for (int g = 0; g < 4; ++g) o[g] = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+            return;
+#endif
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(stage + (ar * 8 + ((2 * g + kh) ^ (ar & 7))) * 4) =
@@ -618,8 +622,12 @@ struct ProjNT {
                     we[e] = 0.f;
                     if constexpr (EPI == EPI_RS_BIAS_ACT) {
                         ve[e] = r0[i] * x + be;
+#ifdef MSF2_DIAG_EPI_NOMATH
+                        if (a.act == 77) ve[e] = 0.f;
+#else
                         if (a.act == 1) ve[e] = silu_f(ve[e]);
                         else if (a.act == 2) ve[e] = sigmoid_f(ve[e]);
+#endif
                         else if (a.act == 3) ve[e] = fmaxf(ve[e], 0.f);
                         else if (a.act == 4) ve[e] = ve[e] >= 0.f ? ve[e] : ve[e] * a.prelu;
                     } else if constexpr (EPI == EPI_NORM) {
@@ -680,7 +688,11 @@ struct ProjNT {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+#ifdef MSF2_DIAG_EPI_NOSTORE
+                if (ok[i] && nok && v[i].x == 123.456f) {
+#else
                 if (ok[i] && nok) {
+#endif
                     const unsigned off = mrow[i] * ldo4 + nc4;
                     if constexpr (RESLDS) {
 #ifdef MSF2_DIAG_EPI_NOSTORE
