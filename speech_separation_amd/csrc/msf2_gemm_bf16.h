@@ -498,6 +498,9 @@ __global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_k
             __builtin_amdgcn_s_barrier();
             prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + ((cons + wr) & (NST - 1)) * STAGE, next_vecs);
             cons += NRES;
+#ifdef MSF2_DIAG_DRAIN_AFTER_EPI
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing-only build: every store acknowledged before the stream goes on
+#endif
             // every wave is done with the residual stages: refill them
             __builtin_amdgcn_s_barrier();
             for (int i = 0; i < NRES; ++i)
