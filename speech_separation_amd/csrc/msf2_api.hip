@@ -253,19 +253,24 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     } else {
         w.t = ar.take<float>(M * C);
     }
-    w.part = ar.take<float>(2L * B * w.nblk);
+    w.part = ar.take<float>(2L * B * (w.nblk + (1 << MSF2_TCN_DEPTH)));     // (the bf16 stage A's block count grows with the dilation)
     w.bstat = ar.take<float>(2L * B);
     return w;
 }
 
-static void launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned short* h16, const msf2_tcn_weights& tw, int C, int dil) {
-    const dim3 grid(w.nblk, c.B), blk(256);
-    switch (C) {   // frames per thread = 32 / (256 / (C / 8))
+// returns the number of partial-sum entries (blocks per utterance) the launch wrote
+static int launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned short* h16, const msf2_tcn_weights& tw, int C, int dil) {
+    // frames per thread NIT = 32 / (256 / (C / 8)); a block holds 256 / (C / 8) thread rows of NIT frames, dil apart
+    const int rows_per_block = 256 / (C / 8), nit = 32 / rows_per_block;
+    const int nblk = cdiv(cdiv(c.S, nit * dil) * dil, rows_per_block);
+    const dim3 grid(nblk, c.B), blk(256);
+    switch (C) {
         case 512: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<8>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
         case 256: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<4>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
         case 128: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<2>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
         default:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<1>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
     }
+    return nblk;
 }
 
 // bf16 mode: inside the block h, t and g*h live in bf16 only (contraction operands, depthwise input
@@ -289,8 +294,8 @@ static int run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned s
     unsigned short* hn16 = w.h16b;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
-        launch_stage_a_bf16(c, w, h16, tw, C, 1 << j);
-        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat, tw.c1, tw.c2, w.c1f, C);
+        const int nb = launch_stage_a_bf16(c, w, h16, tw, C, 1 << j);
+        launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat, tw.c1, tw.c2, w.c1f, C);
         ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
         a.bstat = w.bstat; a.c1f = w.c1f; a.res16 = h16; a.ldr = C; a.out16 = hn16;

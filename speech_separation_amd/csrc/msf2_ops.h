@@ -441,17 +441,22 @@ __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restric
     write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
 }
 
-// bf16 in / bf16 out form of stage A for the bf16 mode: 8 channels (16 bytes) per lane, the
-// NIT frames of a thread fully unrolled with all 3 * NIT row loads issued up front from clamped
-// rows (taps outside the utterance are zeroed by a 0/1 factor, never by a predicated load).
-// grid (ceil(S/32), B), block 256, NIT = 32 / (256 / (C/8)).  Statistics from the fp32 values.
+// bf16 in / bf16 out form of stage A for the bf16 mode: 8 channels (16 bytes) per lane.
+// A thread owns NIT frames that are `dil` apart: base + j dil, j = 0 .. NIT-1, so the taps of one frame are the
+// centre rows of its neighbours and the thread reads NIT + 2 rows instead of 3 NIT (each row of h once, plus two
+// per thread).  Thread row T = blockIdx.x * (256 / lanes per frame) + (threadIdx.x / lanes per frame) maps to
+// segment q = T / dil, residue r = T % dil, base = q * NIT * dil + r: every frame belongs to exactly one (q, j, r).
+// All rows are loaded up front from clamped rows; taps outside the utterance are zeroed by a 0/1 factor, never by
+// a predicated load.  grid (ceil(ceil(S / (NIT dil)) dil / rows per block), B), block 256.  Statistics from the fp32 values.
 template <int NIT>
 __global__ __launch_bounds__(256) void tcn_stage_a_bf16_kernel(const unsigned short* __restrict__ h16, const float* __restrict__ w,
                                                                const float* __restrict__ bias, unsigned short* __restrict__ t16,
                                                                float* __restrict__ part, int S, int C, int dil) {
     __shared__ float red[8];
     const int lpf = C >> 3, cq = threadIdx.x % lpf, fo = threadIdx.x / lpf, nf = 256 / lpf;
-    const int b = blockIdx.y, s0 = blockIdx.x * 32;
+    const int b = blockIdx.y;
+    const int T = blockIdx.x * nf + fo;
+    const int base = (T / dil) * (NIT * dil) + (T % dil);
     const int c = 8 * cq;
     float wk[3][8], bs[8];
 #pragma unroll
@@ -465,31 +470,29 @@ __global__ __launch_bounds__(256) void tcn_stage_a_bf16_kernel(const unsigned sh
         bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
     }
     const unsigned short* hb = h16 + (long)b * S * C + c;
-    uint4 xm[NIT], x0[NIT], xp[NIT];
+    uint4 x[NIT + 2];        // rows base + (j - 1) dil, j = 0 .. NIT + 1
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int s = min(s0 + fo + nf * i, S - 1);
-        xm[i] = *reinterpret_cast<const uint4*>(hb + (long)max(s - dil, 0) * C);
-        x0[i] = *reinterpret_cast<const uint4*>(hb + (long)s * C);
-        xp[i] = *reinterpret_cast<const uint4*>(hb + (long)min(s + dil, S - 1) * C);
+    for (int j = 0; j < NIT + 2; ++j) {
+        const int s = min(max(base + (j - 1) * dil, 0), S - 1);
+        x[j] = *reinterpret_cast<const uint4*>(hb + (long)s * C);
     }
     float sum = 0.f, sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-        const int s = s0 + fo + nf * i;
+    for (int j = 0; j < NIT; ++j) {
+        const int s = base + j * dil;
         const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
-        const unsigned am[4] = {xm[i].x, xm[i].y, xm[i].z, xm[i].w};
-        const unsigned a0[4] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w};
-        const unsigned ap[4] = {xp[i].x, xp[i].y, xp[i].z, xp[i].w};
+        const unsigned am[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+        const unsigned a0[4] = {x[j + 1].x, x[j + 1].y, x[j + 1].z, x[j + 1].w};
+        const unsigned ap[4] = {x[j + 2].x, x[j + 2].y, x[j + 2].z, x[j + 2].w};
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int hbit = 0; hbit < 2; ++hbit) {
-                const int e = 2 * j + hbit;
-                const float m_ = __builtin_bit_cast(float, hbit ? (am[j] & 0xffff0000u) : (am[j] << 16)) * fm;
-                const float z_ = __builtin_bit_cast(float, hbit ? (a0[j] & 0xffff0000u) : (a0[j] << 16));
-                const float p_ = __builtin_bit_cast(float, hbit ? (ap[j] & 0xffff0000u) : (ap[j] << 16)) * fp;
+                const int e = 2 * q + hbit;
+                const float m_ = __builtin_bit_cast(float, hbit ? (am[q] & 0xffff0000u) : (am[q] << 16)) * fm;
+                const float z_ = __builtin_bit_cast(float, hbit ? (a0[q] & 0xffff0000u) : (a0[q] << 16));
+                const float p_ = __builtin_bit_cast(float, hbit ? (ap[q] & 0xffff0000u) : (ap[q] << 16)) * fp;
                 v[e] = silu_f(wk[0][e] * m_ + wk[1][e] * z_ + wk[2][e] * p_ + bs[e]);
             }
         }
