@@ -253,7 +253,7 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     } else {
         w.t = ar.take<float>(M * C);
     }
-    w.part = ar.take<float>(2L * B * (w.nblk + (1 << MSF2_TCN_DEPTH)));     // (the bf16 stage A's block count grows with the dilation)
+    w.part = ar.take<float>(2L * B * (w.nblk + (1 << MSF2_TCN_DEPTH)));     // (stage A's block count grows with the dilation)
     w.bstat = ar.take<float>(2L * B);
     return w;
 }
@@ -334,17 +334,20 @@ static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short*
     float* hn = w.h1;
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
+        int nb;
         {
-            const dim3 grid(w.nblk, c.B), blk(256);
-            const int dil = 1 << j;
-            switch (C) {   // frames per thread = 32 / (256 / (C / 4))
+            // frames per thread NIT = 32 / (256 / (C / 4)); a block holds 256 / (C / 4) thread rows of NIT frames, dil apart
+            const int dil = 1 << j, rows_per_block = 256 / (C / 4), nit = 32 / rows_per_block;
+            nb = cdiv(cdiv(c.S, nit * dil) * dil, rows_per_block);
+            const dim3 grid(nb, c.B), blk(256);
+            switch (C) {
                 case 512: hipLaunchKernelGGL(tcn_stage_a_kernel<16>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
                 case 256: hipLaunchKernelGGL(tcn_stage_a_kernel<8>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
                 case 128: hipLaunchKernelGGL(tcn_stage_a_kernel<4>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
                 default:  hipLaunchKernelGGL(tcn_stage_a_kernel<2>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
             }
         }
-        launch_stats_finalize(c, w.part, w.nblk, (long)c.S * C, 1e-5f, w.bstat);
+        launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
         a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
         a.bstat = w.bstat; a.res = h; a.ldr = C;

@@ -393,49 +393,45 @@ __global__ void kv_finalize_kernel(const float* __restrict__ part, float* __rest
 }
 
 // ---- TCN stage A: t = silu(dwconv3_dilated(h) + bias), + partial sums --------
-// fp32 in / fp32 out: 4 channels (16 bytes) per lane, 32 frames per block; a thread's NIT frames are
-// handled 8 at a time with all 24 row loads of a group issued up front from clamped rows (taps outside
-// the utterance are zeroed by a 0/1 factor, never by a predicated load, which hipcc would wait on in place).
-// grid (ceil(S/32), B), block 256, NIT = 32 / (256 / (C/4)).
+// fp32 in / fp32 out: 4 channels (16 bytes) per lane.  A thread owns NIT frames that are `dil` apart
+// (base + j dil), so the taps of one frame are the centre rows of its neighbours and the thread reads NIT + 2
+// rows instead of 3 NIT; thread row T = blockIdx.x * (256 / lanes per frame) + (threadIdx.x / lanes per frame)
+// maps to base = (T / dil) * NIT * dil + T % dil, which covers every frame exactly once.  All rows are loaded up
+// front from clamped rows (taps outside the utterance are zeroed by a 0/1 factor, never by a predicated load,
+// which hipcc would wait on in place).  grid (ceil(ceil(S / (NIT dil)) dil / rows per block), B), block 256.
 template <int NIT>
 __global__ __launch_bounds__(256) void tcn_stage_a_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ t,
                                                           float* __restrict__ part, int S, int C, int dil) {
     __shared__ float red[8];
     const int lpf = C >> 2, cq = threadIdx.x % lpf, fo = threadIdx.x / lpf, nf = 256 / lpf;
-    const int b = blockIdx.y, s0 = blockIdx.x * 32;
+    const int b = blockIdx.y;
+    const int T = blockIdx.x * nf + fo;
+    const int base = (T / dil) * (NIT * dil) + (T % dil);
     const int c = 4 * cq;
     const float4 w0 = *reinterpret_cast<const float4*>(w + c);
     const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
     const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
     const float4 bs = *reinterpret_cast<const float4*>(bias + c);
     const float* hb = h + (long)b * S * C + c;
+    float4 x[NIT + 2];       // rows base + (j - 1) dil
+#pragma unroll
+    for (int j = 0; j < NIT + 2; ++j)
+        x[j] = *reinterpret_cast<const float4*>(hb + (long)min(max(base + (j - 1) * dil, 0), S - 1) * C);
     float sum = 0.f, sq = 0.f;
-    constexpr int UN = NIT < 8 ? NIT : 8;
 #pragma unroll
-    for (int i0 = 0; i0 < NIT; i0 += UN) {
-        float4 xm[UN], x0[UN], xp[UN];
-#pragma unroll
-        for (int i = 0; i < UN; ++i) {
-            const int s = min(s0 + fo + nf * (i0 + i), S - 1);
-            xm[i] = *reinterpret_cast<const float4*>(hb + (long)max(s - dil, 0) * C);
-            x0[i] = *reinterpret_cast<const float4*>(hb + (long)s * C);
-            xp[i] = *reinterpret_cast<const float4*>(hb + (long)min(s + dil, S - 1) * C);
-        }
-#pragma unroll
-        for (int i = 0; i < UN; ++i) {
-            const int s = s0 + fo + nf * (i0 + i);
-            const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
-            float4 v;
-            v.x = silu_f(w0.x * (xm[i].x * fm) + w1.x * x0[i].x + w2.x * (xp[i].x * fp) + bs.x);
-            v.y = silu_f(w0.y * (xm[i].y * fm) + w1.y * x0[i].y + w2.y * (xp[i].y * fp) + bs.y);
-            v.z = silu_f(w0.z * (xm[i].z * fm) + w1.z * x0[i].z + w2.z * (xp[i].z * fp) + bs.z);
-            v.w = silu_f(w0.w * (xm[i].w * fm) + w1.w * x0[i].w + w2.w * (xp[i].w * fp) + bs.w);
-            if (s < S) {
-                *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
-                sum += v.x + v.y + v.z + v.w;
-                sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            }
+    for (int j = 0; j < NIT; ++j) {
+        const int s = base + j * dil;
+        const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
+        float4 v;
+        v.x = silu_f(w0.x * (x[j].x * fm) + w1.x * x[j + 1].x + w2.x * (x[j + 2].x * fp) + bs.x);
+        v.y = silu_f(w0.y * (x[j].y * fm) + w1.y * x[j + 1].y + w2.y * (x[j + 2].y * fp) + bs.y);
+        v.z = silu_f(w0.z * (x[j].z * fm) + w1.z * x[j + 1].z + w2.z * (x[j + 2].z * fp) + bs.z);
+        v.w = silu_f(w0.w * (x[j].w * fm) + w1.w * x[j + 1].w + w2.w * (x[j + 2].w * fp) + bs.w);
+        if (s < S) {
+            *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = v;
+            sum += v.x + v.y + v.z + v.w;
+            sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
     }
     write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
