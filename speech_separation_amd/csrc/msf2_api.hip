@@ -160,7 +160,7 @@ static bool launch_dwconv17(const Ctx& c, const float* x, int ldx, const float* 
 }
 
 static void launch_dwconv17_bf16(const Ctx& c, const unsigned short* x, int ldx, const float* dw, unsigned short* y, int ldy, int C) {
-    dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW_TS), c.B);
+    dim3 grid(cdiv(C / 4, 128), cdiv(c.S, DW16_TS), c.B);
     hipLaunchKernelGGL(dwconv17_bf16_kernel, grid, dim3(128), 0, c.st, x, ldx, dw, y, ldy, c.S, C);
 }
 

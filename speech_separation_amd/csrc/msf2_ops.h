@@ -293,38 +293,39 @@ __device__ __forceinline__ float4 bf16x4_ld(const unsigned short* p) {
     return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xffff0000u),
                        __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xffff0000u));
 }
-__global__ __launch_bounds__(128, 3) void dwconv17_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
+constexpr int DW16_TS = 32;      // frames per block of the bf16 kernel: 48 row reads per 32 results
+__global__ __launch_bounds__(128, 2) void dwconv17_bf16_kernel(const unsigned short* __restrict__ x, int ldx,
                                                             const float* __restrict__ dw, unsigned short* __restrict__ y,
                                                             int ldy, int S, int C) {
     const int cq = blockIdx.x * 128 + threadIdx.x;
     if (cq >= (C >> 2)) return;
-    const int b = blockIdx.z, s0 = blockIdx.y * DW_TS;
+    const int b = blockIdx.z, s0 = blockIdx.y * DW16_TS;
     float4 w[17];
 #pragma unroll
     for (int k = 0; k < 17; ++k) w[k] = *reinterpret_cast<const float4*>(dw + k * C + 4 * cq);
-    float4 acc[DW_TS];
+    w[8].x += 1.f; w[8].y += 1.f; w[8].z += 1.f; w[8].w += 1.f;      // y = x + conv(x): the centre tap carries the identity
+    float4 acc[DW16_TS];
 #pragma unroll
-    for (int o = 0; o < DW_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = 0; o < DW16_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned short* xb = x + (long)b * S * ldx + 4 * cq;
 #pragma unroll
-    for (int r = -8; r < DW_TS + 8; ++r) {
+    for (int r = -8; r < DW16_TS + 8; ++r) {
         const int s = s0 + r;
         const float inb = (s >= 0 && s < S) ? 1.f : 0.f;      // see dwconv17_kernel
         float4 xv = bf16x4_ld(xb + (long)min(max(s, 0), S - 1) * ldx);
         xv.x *= inb; xv.y *= inb; xv.z *= inb; xv.w *= inb;
 #pragma unroll
-        for (int o = 0; o < DW_TS; ++o) {
-            const int k = r - o + 8;
-            if (k >= 0 && k < 17) {
+        for (int k = 0; k < 17; ++k) {
+            const int o = r - k + 8;             // the result row this input row feeds through tap k
+            if (o >= 0 && o < DW16_TS) {
                 acc[o].x += w[k].x * xv.x; acc[o].y += w[k].y * xv.y;
                 acc[o].z += w[k].z * xv.z; acc[o].w += w[k].w * xv.w;
             }
-            if (r == o) { acc[o].x += xv.x; acc[o].y += xv.y; acc[o].z += xv.z; acc[o].w += xv.w; }
         }
     }
     unsigned short* yb = y + (long)b * S * ldy + 4 * cq;
 #pragma unroll
-    for (int o = 0; o < DW_TS; ++o) {
+    for (int o = 0; o < DW16_TS; ++o) {
         const int s = s0 + o;
         if (s < S) {
             uint2 h;
