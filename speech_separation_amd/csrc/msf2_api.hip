@@ -2,6 +2,7 @@
 // MossFormer2_SS forward pass.  All work is enqueued on the caller's stream;
 // nothing here allocates, synchronises or keeps mutable global state -- except the
 // opt-in kernel timer below (off by default, a measurement aid for one thread).
+#include <cstring>
 #include <vector>
 #include "msf2_common.h"
 #include "msf2_gemm.h"
@@ -97,6 +98,28 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             // widest output): measured 6 % / 2 % faster than the 256 x 256 form there, equal elsewhere
             const int geom2_env = getenv("MSF2_GEOM2") ? atoi(getenv("MSF2_GEOM2")) : -1;
             const bool geom2 = geom2_env >= 0 ? geom2_env != 0 : (EPI == EPI_BIAS_RES || a.N > 1024);
+            // 128 x 128 tiles with a short ring, three or four workgroups per CU: more waves to cover the copy latency than
+            // the large tiles have.  Measured at 64 x 4 s: the N = 2176 projection 7 % faster with three per CU (four spill
+            // there), the plain N = 512 projections 12 % faster with four; the others equal or slower.
+            // MSF2_GEOM3 / MSF2_GEOM4 name the kernels that take them ('a' + EPI for token-shifted A, '0' + EPI otherwise).
+            const char* g3 = getenv("MSF2_GEOM3") ? getenv("MSF2_GEOM3") : "a";
+            const char* g4 = getenv("MSF2_GEOM4") ? getenv("MSF2_GEOM4") : "0";
+            const char key = (AMODE ? 'a' : '0') + EPI;
+            const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 1024;
+            if (want && many && strchr(g4, key)) {
+                typedef DmaGeom<P, 4> G4;
+                dim3 g(cdiv(a.N, G4::BNX), cdiv(c.S, G4::BMX), c.B);
+                al.ncol_loop = 1;
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 4>), g, dim3(G4::THREADS), 0, c.st, al);
+                return a.sq_part ? G4::TN * 32 : 0;
+            }
+            if (want && many && strchr(g3, key)) {
+                typedef DmaGeom<P, 3> G3;
+                dim3 g(cdiv(a.N, G3::BNX), cdiv(c.S, G3::BMX), c.B);
+                al.ncol_loop = 1;
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 3>), g, dim3(G3::THREADS), 0, c.st, al);
+                return a.sq_part ? G3::TN * 32 : 0;
+            }
             if (want && geom2 && (long)cdiv(a.N, 256) * cdiv(c.S, 128) * c.B >= 1024) {
                 typedef DmaGeom<P, 2> G2;
                 dim3 g2(cdiv(a.N, G2::BNX), cdiv(c.S, G2::BMX), c.B);

@@ -211,20 +211,34 @@ template <class P> struct DmaGeom<P, 2> {
     static constexpr int BMX = 128, BNX = 256, NWX = 256, NST = 3, MINB = 2;
 };
 
+//   BIG = 3: 128 x 128 tile, 4 waves, 3-slot ring with the epilogue tiles over slot 0 (48 KB), THREE workgroups per CU
+//            (at most 168 registers per lane).
+template <class P> struct DmaGeom<P, 3> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 2;
+    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 3, MINB = 3;
+};
+
+//   BIG = 4: as BIG = 3 with a 2-slot ring (32 KB): FOUR workgroups per CU, at most 128 registers per lane.
+template <class P> struct DmaGeom<P, 4> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 2;
+    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 2, MINB = 4;
+};
+
 template <class P, int BIG>
-__global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_kernel_bf16_dma(const typename P::Args args) {
+__global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
-    static_assert(BIG == 0 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
+    constexpr bool SMALL = (BIG == 0);                  // the 128 x 128 stream form: several column tiles, both products, residual tiles
+    static_assert(SMALL || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
     constexpr int TILE_A = G::BMX * 64, TILE_B = G::BNX * 64, STAGE = TILE_A + TILE_B;   // bytes
     constexpr int PA = G::BMX / 16 / NWAVES, PB = G::BNX / 16 / NWAVES;                  // copies per wave and k tile: 16 rows x 64 B each
     constexpr int DMA_PER_TILE = PA + PB;
     static_assert(PA >= 1 && PB >= 1 && PA * 16 * NWAVES == G::BMX && PB * 16 * NWAVES == G::BNX, "tile rows must split evenly over the waves");
-    constexpr bool STAGE_IN_RING = (BIG == 2);    // the epilogue tiles lie over slot 0 (no copy is in flight by then)
+    constexpr bool STAGE_IN_RING = (BIG >= 2 && BIG <= 4);    // the epilogue tiles lie over slot 0 (no copy is in flight by then)
     static_assert(!STAGE_IN_RING || NWAVES * 4096 <= STAGE, "the epilogue tiles must fit one ring slot");
     __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + (STAGE_IN_RING ? 0 : NWAVES * 4096)];   // ring (+ one 4 KiB epilogue tile per wave)
     P prob;
-    if constexpr (BIG) prob.init_tile(args, G::BMX, G::NWX);
+    if constexpr (!SMALL) prob.init_tile(args, G::BMX, G::NWX);
     else prob.init(args);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / G::WC, wc = wave % G::WC;
@@ -237,13 +251,13 @@ __global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_k
     // tiles of each column tile and is read from LDS.  Loaded from global memory by the epilogue itself
     // it queues behind the ~96 KB of operand copies the CU has in flight: those 16 loads cost more
     // cycles than the 32 K steps.
-    constexpr bool RESLDS = (BIG == 0) && (P::NSEG == 2);
+    constexpr bool RESLDS = SMALL && (P::NSEG == 2);
     constexpr int NRES = RESLDS ? 2 : 0;
-    static_assert(!RESLDS || (STAGE == 16384 && DMA_PER_TILE == 4), "residual tiles reuse the ring stage and its copy count");
+    static_assert(!RESLDS || (STAGE == 16384 && DMA_PER_TILE * NWAVES == 16), "residual tiles reuse the ring stage and its copy count");
     const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG, nstream = nkt + NRES;
     // the 256-row geometry is launched with one column tile per workgroup (walking several gains 4 % from the
     // prefetch across epilogues and loses 20 % to the registers the next tile's column vectors take)
-    constexpr bool MULTI = (BIG == 0);
+    constexpr bool MULTI = SMALL;
     const int nrep = MULTI ? prob.col_tiles_here(G::NWX) : 1;
     const int total = nrep * nstream;
     // ring slot of stream tile i (NST is 4 or 3)
@@ -312,8 +326,8 @@ __global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_k
             // residual rows 64 r .. 64 r + 63: one copy = 4 rows x 256 B, chunk swizzled on the source side
             const int r = pf_t - nkt;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int inst = wave * 4 + i;
+            for (int i = 0; i < DMA_PER_TILE; ++i) {
+                const int inst = wave * DMA_PER_TILE + i;
                 const int row = inst * 4 + (lane >> 4);
                 const int chunk = (lane & 15) ^ (row & 7);
                 dma16(pf.ptrRes16(64 * r + row, chunk * 8), __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(BIG == 1 ? 512 : 256, BIG == 1 ? 1 : 2) void gemm_k
             // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
             wait_tile(cons + 1);
             __builtin_amdgcn_s_barrier();
-            prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + ((cons + wr) & (NST - 1)) * STAGE, next_vecs);
+            prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + slot(cons + (wr * TM) / 2) * STAGE + ((wr * TM) & 1) * (32 * 256), next_vecs);
             cons += NRES;
 #ifdef MSF2_DIAG_DRAIN_AFTER_EPI
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing-only build: every store acknowledged before the stream goes on

@@ -303,7 +303,7 @@ def test_bf16_full_model_si_sdr(golden_dir):
 
 def test_bf16_kernel_choices_agree():
     """The bf16 projections pick their kernel by problem size (register-staged, 128 x 128 global->LDS ring with
-    1 or 2 column tiles per workgroup, 256 x 256 8-wave geometry, 128 x 256 geometry).  Every choice performs the same arithmetic
+    1 or 2 column tiles per workgroup, 256 x 256 8-wave geometry, 128 x 256 geometry, 128 x 128 with a 3- or 2-slot ring).  Every choice performs the same arithmetic
     in the same order per output element, so a gated TCN block at a size that enables all of them must
     not depend on which one ran."""
     g = torch.Generator().manual_seed(21)
@@ -313,20 +313,31 @@ def test_bf16_kernel_choices_agree():
     pk = PackedWeights(sd, cfg1, DEV, BF)
     x = torch.randn(B, S, C, generator=g).to(DEV)
     outs = {}
-    for name, env in (("default", {}), ("no_big", {"MSF2_NO_BIG": "1"}), ("loop1", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "1"}),
-                      ("loop4", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "4"}),
-                      ("geom2_all", {"MSF2_GEOM2": "1"}), ("geom2_none", {"MSF2_GEOM2": "0"})):
-        for k in ("MSF2_NO_BIG", "MSF2_NCOL_LOOP", "MSF2_GEOM2"):
+    # the token-shifted N = 2176 projection (not part of the TCN block) at a size where every geometry is eligible
+    xs = torch.randn(8, S, C, generator=g).to(DEV)
+    W = (torch.randn(2176, C, generator=g) / C ** 0.5).to(DEV)
+    bias = (torch.randn(2176, generator=g) * 0.1).to(DEV)
+    outs_p = {}
+    variants = (("default", {}), ("no_big", {"MSF2_NO_BIG": "1"}), ("loop1", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "1"}),
+                ("loop4", {"MSF2_NO_BIG": "1", "MSF2_NCOL_LOOP": "4"}),
+                ("geom2_all", {"MSF2_GEOM2": "1", "MSF2_GEOM3": "n", "MSF2_GEOM4": "n"}),
+                ("geom1_all", {"MSF2_GEOM2": "0", "MSF2_GEOM3": "n", "MSF2_GEOM4": "n"}),
+                ("geom3_all", {"MSF2_GEOM3": "a0123", "MSF2_GEOM4": "n"}), ("geom4_all", {"MSF2_GEOM4": "a0123"}))
+    knobs = ("MSF2_NO_BIG", "MSF2_NCOL_LOOP", "MSF2_GEOM2", "MSF2_GEOM3", "MSF2_GEOM4")
+    for name, env in variants:
+        for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
             outs[name] = ops.gated_tcn(x.clone(), pk.layers[0], precision=BF)
+            outs_p[name] = ops.linear(xs, W, bias, shift=True, scale_norm=True, act=1, precision=BF)
         finally:
             for k in env:
                 os.environ.pop(k, None)
-    assert torch.isfinite(outs["default"]).all()
-    for name in ("no_big", "loop1", "loop4", "geom2_all", "geom2_none"):
+    assert torch.isfinite(outs["default"]).all() and torch.isfinite(outs_p["default"]).all()
+    for name, _ in variants[1:]:
         assert torch.equal(outs[name], outs["default"]), name
+        assert torch.equal(outs_p[name], outs_p["default"]), name + " (projection)"
 
 
 def test_bf16_batch_independence():
