@@ -581,25 +581,31 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     hipLaunchKernelGGL(final_ln_kernel, dim3(w.nblk_ln, B), dim3(256), 0, c.st, w.x, wt->fin_ln_w, wt->fin_ln_b, w.part, S, C, 1e-6f);
     launch_stats_finalize(c, w.part, w.nblk_ln, (long)S * C, 1e-8f, w.bstat);
     hipLaunchKernelGGL(final_gn_kernel, dim3(cdiv(MC / 4, 256)), dim3(256), 0, c.st, w.x, w.skip, w.bstat, wt->fin_gn_w,
-                       wt->fin_gn_b, wt->prelu_a, w.po, tp.mdl, c.M, S, C);
+                       wt->fin_gn_b, wt->prelu_a, w.po, tp.mdl, c.M, S, C, w.x16);
 
     // mask head
     float* z = w.hu_pre;                 // [M, 2C]
     float* zz = w.hu;                    // [2][M, C]
     float* sep = w.hu_pre + c.M * 2 * C; // [2][M, C]
+    // bf16 mode: each stage also writes the bf16 image the next contraction reads (into buffers the layers are done with)
+    unsigned short* y16 = w.x16;         // [M, C]
+    unsigned short* z16 = w.hu_pre16;    // [M, 2C]
+    unsigned short* zz16 = w.hu16;       // [2][M, C]
     {
         ProjArgs a = proj_args(w.po, C, wt->w_co, C, 2 * C, S, z, 2 * C);
-        a.bias = wt->b_co; a.act = 0;
+        a.bias = wt->b_co; a.act = 0; a.A16 = y16; a.out16 = z16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     for (int sp = 0; sp < 2; ++sp) {
         {
             ProjArgs a = proj_args(z + sp * C, 2 * C, wt->w_o, C, C, S, zz + sp * MC, C);
             a.W2 = wt->w_og; a.bias = wt->b_o; a.bias2 = wt->b_og;
+            if (z16) { a.A16 = z16 + sp * C; a.out16 = zz16 + sp * MC; }
             launch_proj<A_PLAIN, EPI_TANH_SIG>(c, a);
         }
         {
             ProjArgs a = proj_args(zz + sp * MC, C, wt->w_cd, C, C, S, sep + sp * MC, C);
+            if (zz16) a.A16 = zz16 + sp * MC;
             a.res = w.enc; a.ldr = C; a.out2 = sp == 0 ? tp.mask0 : tp.mask1;
             launch_proj<A_PLAIN, EPI_RELU_MUL>(c, a);
         }

@@ -590,11 +590,11 @@ __global__ __launch_bounds__(256) void final_ln_kernel(float* __restrict__ x, co
 }
 
 // ---- out = prelu(GroupNorm(y) + skip); optional tap of the pre-PReLU value ---
-// flat over M*C/4 float4s
+// flat over M*C/4 float4s; out16: optional bf16 image of out (operand of the next contraction in bf16 mode)
 __global__ void final_gn_kernel(const float* __restrict__ y, const float* __restrict__ skip,
                                 const float* __restrict__ stats, const float* __restrict__ gw,
                                 const float* __restrict__ gb, float prelu_a, float* __restrict__ out,
-                                float* __restrict__ tap, long M, int S, int C) {
+                                float* __restrict__ tap, long M, int S, int C, unsigned short* __restrict__ out16) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = C >> 2;
     if (i >= M * nq) return;
@@ -617,6 +617,12 @@ __global__ void final_gn_kernel(const float* __restrict__ y, const float* __rest
     r.z = r.z >= 0.f ? r.z : prelu_a * r.z;
     r.w = r.w >= 0.f ? r.w : prelu_a * r.w;
     *reinterpret_cast<float4*>(out + m * C + c) = r;
+    if (out16) {
+        uint2 h;
+        h.x = pk_bf16_pair(r.x, r.y);
+        h.y = pk_bf16_pair(r.z, r.w);
+        *reinterpret_cast<uint2*>(out16 + m * C + c) = h;
+    }
 }
 
 // ---- decoder stage 1: fv[m][k] = sum_c sep[m][c] * W[c][k], one wave per frame
