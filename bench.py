@@ -59,6 +59,35 @@ def measured_traffic(precision, B, T):
         return None
 
 
+def secondary_bf16(cfg, sd, dev, T, seconds, refn0, B=64, steps=3, warmup=2):
+    """bf16 MFMA mode on batch 64: whole-forward throughput and, when the CPU reference of utterance 0 is at
+    hand, the SI-SDR difference to it (the contract for this mode is 0.05 dB)."""
+    from speech_separation_amd import _lib
+    from speech_separation_amd.model import MossFormerHIP
+    from speech_separation_amd.synth import synth_batch, synth_mixture, permute_si_sdr
+    model = MossFormerHIP(cfg, compute_device=dev, precision=_lib.PREC_BF16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    x = torch.from_numpy(synth_batch(B, T, seed0=0)).to(dev)
+    for _ in range(warmup):
+        out = model(x)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model(x)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    rec = {"value": B * T / 8000.0 * steps / dt, "unit": "audio-s/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt / steps,
+           "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {seconds:g} s mixtures, bf16 MFMA path"}}
+    if refn0 is not None:
+        got = torch.stack(out, 0)[:, :1].cpu().numpy()
+        mix, s1, s2 = synth_mixture(T, 0)
+        rec["si_sdr_delta_db"] = (permute_si_sdr(got[0, 0], got[1, 0], s1, s2)
+                                  - permute_si_sdr(refn0[0, 0], refn0[1, 0], s1, s2))
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +98,8 @@ def main():
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="fp32: exact fp32 MFMA (the headline configuration); bf16: bf16 MFMA operands, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the extra bf16 batch-64 measurement that the default single-GPU fp32 run appends as 'secondary'")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,6 +213,12 @@ def main():
                                    "sample": f"one {a.seconds:g} s mixture (batch 1), fp32, one pass, oracle/cpu_ref.py"}
             res["max_abs_err_vs_cpu"] = float(np.abs(got - refn).max())
             res["si_sdr_delta_db"] = sdr_gpu - sdr_cpu
+        if world == 1 and prec == _lib.PREC_FP32 and not a.no_secondary:
+            # the bf16 MFMA configuration (batch 64 of the same mixtures), measured the same way, as a second record
+            refn0 = refn if "cpu_baseline" in res else None
+            del model
+            torch.cuda.empty_cache()
+            res["secondary"] = secondary_bf16(cfg, sd, dev, T, a.seconds, refn0)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
