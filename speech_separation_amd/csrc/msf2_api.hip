@@ -45,11 +45,32 @@ static inline bool fits32(long rows, long ld) { return rows * ld * 4 < (1L << 32
 constexpr int ENC_TS = 32;    // frames per block in the encoder / TCN stage A kernels
 constexpr int TCN_TS = 32;
 
+// Diagnostic kernel-choice switches, read from the environment once per API call (none changes results).
+struct Knobs {
+    int ncol_loop = 2;          // MSF2_NCOL_LOOP: column tiles per workgroup of the 128 x 128 stream form
+    int big_maxn = 4096;        // MSF2_BIG_MAXN: widest projection that may leave that form
+    bool no_big = false;        // MSF2_NO_BIG: 128 x 128 stream form only
+    int geom2 = -1;             // MSF2_GEOM2: 0 / 1 forces the 128 x 256 geometry off / on
+    char g3[16] = "a";          // MSF2_GEOM3 / MSF2_GEOM4: projections that take the 3- / 4-workgroup geometries,
+    char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
+};
+static Knobs read_knobs() {
+    Knobs k;
+    if (const char* e = getenv("MSF2_NCOL_LOOP")) k.ncol_loop = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char* e = getenv("MSF2_BIG_MAXN")) k.big_maxn = atoi(e);
+    k.no_big = getenv("MSF2_NO_BIG") != nullptr;
+    if (const char* e = getenv("MSF2_GEOM2")) k.geom2 = atoi(e);
+    if (const char* e = getenv("MSF2_GEOM3")) { strncpy(k.g3, e, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }
+    if (const char* e = getenv("MSF2_GEOM4")) { strncpy(k.g4, e, sizeof(k.g4) - 1); k.g4[sizeof(k.g4) - 1] = 0; }
+    return k;
+}
+
 struct Ctx {
     hipStream_t st;
     int B, S, T;
     long M;
     int prec = MSF2_PREC_FP32;
+    Knobs k = read_knobs();
 };
 
 // launch the fp32 or the bf16 build of a contraction
@@ -83,8 +104,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
         // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all
         // 4 tiles re-reads A from the fabric 4 times (FETCH_SIZE 2.4 GB instead of 0.9 GB per launch).
-        int loop = 2;
-        if (const char* e = getenv("MSF2_NCOL_LOOP")) loop = atoi(e) > 0 ? atoi(e) : 1;
+        int loop = c.k.ncol_loop;
         ProjArgs al = a;
         if constexpr (!P::PAIRED && P::NSEG == 1) {
             // 256-row tiles, one 8-wave workgroup per CU, when that still gives every CU several tiles
@@ -92,18 +112,16 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             dim3 gb(cdiv(a.N, G::BNX), cdiv(c.S, G::BMX), c.B);
             // measured at 64 x 4 s: 8 % faster for the single-product N = 512 projections, 5 % for the N = 2176 one
             // (its ninth 256-column tile half empty); the two-product TCN contraction keeps the 128 x 128 form
-            const int big_maxn = getenv("MSF2_BIG_MAXN") ? atoi(getenv("MSF2_BIG_MAXN")) : 4096;
-            const bool want = a.N <= big_maxn && getenv("MSF2_NO_BIG") == nullptr;
+            const bool want = a.N <= c.k.big_maxn && !c.k.no_big;
             // 128 x 256 tiles, two workgroups per CU, where the epilogue weighs most (residual read + two writes; the
             // widest output): measured 6 % / 2 % faster than the 256 x 256 form there, equal elsewhere
-            const int geom2_env = getenv("MSF2_GEOM2") ? atoi(getenv("MSF2_GEOM2")) : -1;
-            const bool geom2 = geom2_env >= 0 ? geom2_env != 0 : (EPI == EPI_BIAS_RES || a.N > 1024);
+            const bool geom2 = c.k.geom2 >= 0 ? c.k.geom2 != 0 : (EPI == EPI_BIAS_RES || a.N > 1024);
             // 128 x 128 tiles with a short ring, three or four workgroups per CU: more waves to cover the copy latency than
             // the large tiles have.  Measured at 64 x 4 s: the N = 2176 projection 7 % faster with three per CU (four spill
             // there), the plain N = 512 projections 12 % faster with four; the others equal or slower.
             // MSF2_GEOM3 / MSF2_GEOM4 name the kernels that take them ('a' + EPI for token-shifted A, '0' + EPI otherwise).
-            const char* g3 = getenv("MSF2_GEOM3") ? getenv("MSF2_GEOM3") : "a";
-            const char* g4 = getenv("MSF2_GEOM4") ? getenv("MSF2_GEOM4") : "0";
+            const char* g3 = c.k.g3;
+            const char* g4 = c.k.g4;
             const char key = (AMODE ? 'a' : '0') + EPI;
             const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 1024;
             if (want && many && strchr(g4, key)) {
