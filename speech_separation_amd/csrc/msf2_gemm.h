@@ -1040,6 +1040,16 @@ struct AttnOutT {
         if constexpr (HU16) return mul4(ldg4_bf16_off(reinterpret_cast<const unsigned short*>(a.hu) + oq, 0u), m);
         else return mul4(ld4(a.hu + oq), m);
     }
+    // bf16 kernel, value rows of the group (segment 0) when they are bf16: the packed words themselves, zero past the utterance end
+    template <int SEG> static constexpr bool b_rc16() { return HU16 && SEG == 0; }
+    __device__ uint2 fetchB16(int seg, int kt, int c, int ko) const {
+        const int e = (c < BN / 2) ? (j0 + c) : (a.E + j0 + c - BN / 2);
+        const int s = g * MSF2_GROUP + kt * BK + ko;
+        const long oq = ((long)b * a.S + min(s, a.S - 1)) * a.ldhu + e;
+        uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.hu) + oq);
+        if (s >= a.S) v = make_uint2(0u, 0u);
+        return v;
+    }
     // Accumulators are transposed (ACC_T): each 32 x 32 tile goes through the wave's 4 KiB LDS tile into row-major
     // registers (lane l: rows 8 i + (l >> 3), columns 4 (l & 7) + 0..3), so v, u and o move as 8-byte (bf16) or
     // 16-byte (fp32) vectors, 8 rows x 32 columns per wave instruction.  All v / u loads are issued up front

@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
 __device__ __forceinline__ int bf_swz(int row) { return (row >> 2) & 3; }
 constexpr int BF_TILE = BM * BK * 2;   // bytes of one 128 x 32 bf16 operand tile
 
-enum { SRC_KC_F32 = 0, SRC_KC_BF16 = 1, SRC_RC_F32 = 2 };
+enum { SRC_KC_F32 = 0, SRC_KC_BF16 = 1, SRC_RC_F32 = 2, SRC_RC_BF16 = 3 };   // RC_BF16: row-contiguous bf16 B operand, kept packed
 
 template <class P, int SEG, bool IS_A, int SRC>
 __device__ __forceinline__ void bf_fetch(const P& prob, int kt, int tid, float4 (&r)[4]) {
@@ -52,6 +52,14 @@ __device__ __forceinline__ void bf_fetch(const P& prob, int kt, int tid, float4 
             if constexpr (IS_A) v = *reinterpret_cast<const uint4*>(prob.ptrA16(SEG, kt, e >> 2, (e & 3) * 8));
             else v = *reinterpret_cast<const uint4*>(prob.ptrB16(SEG, kt, e >> 2, (e & 3) * 8));
             r[i] = __builtin_bit_cast(float4, v);
+        }
+    } else if constexpr (SRC == SRC_RC_BF16) {
+        static_assert(!IS_A, "packed row-contiguous source: B operand only");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // 4 consecutive columns of k row 4 kq + i as two packed words in .x / .y
+            const uint2 v = prob.fetchB16(SEG, kt, (tid & 31) * 4, (tid >> 5) * 4 + i);
+            r[i].x = __builtin_bit_cast(float, v.x);
+            r[i].y = __builtin_bit_cast(float, v.y);
         }
     } else {
 #pragma unroll
@@ -79,6 +87,20 @@ __device__ __forceinline__ void bf_put(char* tile, int tid, const float4 (&r)[4]
             const int e = tid + 256 * i, row = e >> 2, ch = e & 3;
             *reinterpret_cast<uint4*>(tile + row * 64 + ((ch ^ bf_swz(row)) << 4)) = __builtin_bit_cast(uint4, r[i]);
         }
+    } else if constexpr (SRC == SRC_RC_BF16) {
+        // the same 4 x 4 transpose on packed values: byte permutes instead of unpack, scale and repack
+        const int kq = tid >> 5, nq = tid & 31;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * nq + c;
+            const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;      // high / low halves of (second, first) operand
+            const unsigned w0 = __builtin_bit_cast(unsigned, (c < 2) ? r[0].x : r[0].y), w1 = __builtin_bit_cast(unsigned, (c < 2) ? r[1].x : r[1].y);
+            const unsigned w2 = __builtin_bit_cast(unsigned, (c < 2) ? r[2].x : r[2].y), w3 = __builtin_bit_cast(unsigned, (c < 2) ? r[3].x : r[3].y);
+            uint2 v;
+            v.x = __builtin_amdgcn_perm(w1, w0, sel);
+            v.y = __builtin_amdgcn_perm(w3, w2, sel);
+            *reinterpret_cast<uint2*>(tile + row * 64 + (((kq >> 1) ^ bf_swz(row)) << 4) + (kq & 1) * 8) = v;
+        }
     } else {
         // r[i] = 4 consecutive rows at k = 4*kq + i: transpose so each row gets its 4 consecutive k
         const int kq = tid >> 5, nq = tid & 31;
@@ -98,15 +120,18 @@ __device__ __forceinline__ bf16x8_t bf_frag(const char* tile, int row, int step,
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <class P> struct BfSrc {
+// whether K segment SEG of P reads its row-contiguous B operand as packed bf16 (P::b_rc16<SEG>() where a problem states it)
+template <class P, int SEG, class = void> struct RcB16 { static constexpr bool V = false; };
+template <class P, int SEG> struct RcB16<P, SEG, decltype((void)P::template b_rc16<SEG>())> { static constexpr bool V = P::template b_rc16<SEG>(); };
+template <class P, int SEG = 0> struct BfSrc {
     static constexpr int A = P::A_BF16 ? SRC_KC_BF16 : ((P::A_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32);
-    static constexpr int B = P::B_BF16 ? SRC_KC_BF16 : ((P::B_ORI == ORI_KC) ? SRC_KC_F32 : SRC_RC_F32);
+    static constexpr int B = P::B_BF16 ? SRC_KC_BF16 : ((P::B_ORI == ORI_KC) ? SRC_KC_F32 : (RcB16<P, SEG>::V ? SRC_RC_BF16 : SRC_RC_F32));
 };
 
 template <class P, int SEG, int TM, int TN>
 __device__ __forceinline__ void run_segment_bf16(const P& prob, char* smA, char* smB, f32x16 (&acc)[TM][TN],
                                                  int tid, int lane, int wr, int wc) {
-    constexpr int SA = BfSrc<P>::A, SB = BfSrc<P>::B;
+    constexpr int SA = BfSrc<P, SEG>::A, SB = BfSrc<P, SEG>::B;
     const int nk = prob.nk(SEG);
     float4 ra[4], rb[4];
     bf_fetch<P, SEG, true, SA>(prob, 0, tid, ra);
