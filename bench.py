@@ -5,90 +5,34 @@
 One step = one forward pass over a batch of synthetic 8 kHz two-speaker
 mixtures already resident in HBM (the configuration the headline metric is
 quoted on: batch 16 of 4-second mixtures, fp32).  With N > 1 every rank (one
-process per GPU, launched by torch.distributed.run) separates its own batch --
-utterances are independent, so the path shards with no data-path collective;
-the only exchange is the gather of the separated waveforms and SI-SDR sums,
-done over RCCL after the timed region's compute and included in it.
+process per GPU) separates its own batch -- utterances are independent, so the
+path shards with no data-path collective; the only exchange is the gather of
+the separated waveforms over RCCL after each step's compute, inside the timed
+region.
+
+Launching: under ``torch.distributed.run`` the ranks are the processes it
+started (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+Started plainly with ``--gpus N`` (N > 1) this process only LAUNCHES: it starts
+N fresh children, one per GPU, before anything here touches a GPU, waits for
+them and exits with the first failure; rank 0's JSON line is the output.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+PMC_FILE = os.path.join(ROOT, "profiles", "tcn_pointwise_pmc.json")
 
 
-def dominant_kernel_probe(model, step, B, T):
-    """Average launch duration of the dominant kernel -- the fused pointwise half of a TCN
-    block (gemm_kernel<ProjNT<0,5>> in fp32, gemm_kernel_bf16_dma<ProjNT<0,5>> in bf16):
-    [B*S, 512] x two 512x512 weights with the gate / GroupNorm / residual epilogue, 8 launches
-    per layer x 24 layers = 53 % of the forward's FLOPs.  Measured in place: one more step of
-    the benchmark workload runs with the library's kernel timer on, which brackets each of its
-    192 launches with HIP events on the stream they are launched on."""
-    import ctypes
-    from speech_separation_amd import _lib
-    lib = _lib.load()
-    S = lib.msf2_num_frames(T)
-    C = model.cfg.dim
-    _lib.check(lib.msf2_timing_begin())
-    step()
-    total, n = ctypes.c_double(0.0), ctypes.c_int(0)
-    _lib.check(lib.msf2_timing_end(ctypes.byref(total), ctypes.byref(n)))
-    if n.value == 0:
-        raise SystemExit("kernel timer saw no launch of the TCN pointwise kernel")
-    flops = 2.0 * B * S * 2 * C * C          # two [M,C]x[C,C] products per launch
-    return total.value / n.value, flops, n.value
-
-
-def measured_traffic(precision, B, T):
-    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/
-    (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs, FETCH_SIZE doubled as gfx950
-    requires); None when no measurement exists for this precision and shape."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_tcn_pointwise_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)[f"{precision}_b{B}_t{T}"]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def secondary_bf16(cfg, sd, dev, T, seconds, refn0, B=64, steps=3, warmup=2):
-    """bf16 MFMA mode on batch 64: whole-forward throughput and, when the CPU reference of utterance 0 is at
-    hand, the SI-SDR difference to it (the contract for this mode is 0.05 dB)."""
-    from speech_separation_amd import _lib
-    from speech_separation_amd.model import MossFormerHIP
-    from speech_separation_amd.synth import synth_batch, synth_mixture, permute_si_sdr
-    model = MossFormerHIP(cfg, compute_device=dev, precision=_lib.PREC_BF16)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model.eval()
-    x = torch.from_numpy(synth_batch(B, T, seed0=0)).to(dev)
-    for _ in range(warmup):
-        out = model(x)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = model(x)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    rec = {"value": B * T / 8000.0 * steps / dt, "unit": "audio-s/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
-           "ms_per_step": 1e3 * dt / steps,
-           "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {seconds:g} s mixtures, bf16 MFMA path"}}
-    if refn0 is not None:
-        got = torch.stack(out, 0)[:, :1].cpu().numpy()
-        mix, s1, s2 = synth_mixture(T, 0)
-        rec["si_sdr_delta_db"] = (permute_si_sdr(got[0, 0], got[1, 0], s1, s2)
-                                  - permute_si_sdr(refn0[0, 0], refn0[1, 0], s1, s2))
-    return rec
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -99,66 +43,253 @@ def main():
                     help="fp32: exact fp32 MFMA (the headline configuration); bf16: bf16 MFMA operands, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the extra bf16 batch-64 measurement that the default single-GPU fp32 run appends as 'secondary'")
-    a = ap.parse_args()
+                    help="skip the extra records the default single-GPU fp32 run appends (bf16 batch 64, batch-1 latency)")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="control-flow rehearsal without a GPU: gloo backend, CPU tensors and a trivial stand-in for the "
+                         "model (checks launching, collectives per rank and the JSON line; measures nothing)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher (no GPU call, no torch import on this path)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Start n fresh copies of this script, one per GPU, and wait for them.  The parent never
+    touches a GPU (a process that has initialised the GPU must not be replaced or forked into
+    ranks).  Returns the exit code: 0 when every rank succeeded."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 writes the JSON line to our stdout; the other ranks have nothing to print
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()             # the exact children started above
+        if pending:
+            time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# measurement helpers
+# ------------------------------------------------------------------------------------------------
+def dominant_kernel_probe(model, forward_once, B, T):
+    """Average launch duration of the dominant kernel -- the fused pointwise half of a TCN
+    block (gemm_kernel<ProjNT<0,5>> in fp32, gemm_kernel_bf16_dma<ProjNT<0,5>> in bf16):
+    [B*S, 512] x two 512x512 weights with the gate / GroupNorm / residual epilogue, 8 launches
+    per layer x 24 layers = 53 % of the forward's FLOPs.  Measured in place: one more forward of
+    the benchmark workload runs with the library's kernel timer on, which brackets each of its
+    192 launches with HIP events on the stream they are launched on.  `forward_once` must not
+    contain a collective: only rank 0 runs the probe."""
+    import ctypes
+    from speech_separation_amd import _lib
+    lib = _lib.load()
+    S = lib.msf2_num_frames(T)
+    C = model.cfg.dim
+    _lib.check(lib.msf2_timing_begin())
+    forward_once()
+    total, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    _lib.check(lib.msf2_timing_end(ctypes.byref(total), ctypes.byref(n)))
+    if n.value == 0:
+        raise SystemExit("kernel timer saw no launch of the TCN pointwise kernel")
+    flops = 2.0 * B * S * 2 * C * C          # two [M,C]x[C,C] products per launch
+    return total.value / n.value, flops, n.value
+
+
+def measured_traffic(precision, B, T, lib_version):
+    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/
+    (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs, FETCH_SIZE doubled as gfx950
+    requires).  None when no measurement exists for this precision and shape, or when it was taken
+    on another version of the library (the kernel may have changed since)."""
+    try:
+        with open(PMC_FILE) as f:
+            rec = json.load(f)[f"{precision}_b{B}_t{T}"]
+        if int(rec.get("lib_version", -1)) != int(lib_version):
+            return None
+        return rec["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def timed_forwards(model, x, dev, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        out = model(x)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model(x)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps, out
+
+
+def secondary_bf16(cfg, sd, dev, T, seconds, refn0, B=64, steps=3, warmup=2):
+    """bf16 MFMA mode on batch 64: whole-forward throughput and, when the CPU reference of utterance 0 is at
+    hand, the SI-SDR difference to it (the contract for this mode is 0.05 dB)."""
+    import torch
+    from speech_separation_amd import _lib
+    from speech_separation_amd.model import MossFormerHIP
+    from speech_separation_amd.synth import synth_batch, synth_mixture, permute_si_sdr
+    model = MossFormerHIP(cfg, compute_device=dev, precision=_lib.PREC_BF16)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    x = torch.from_numpy(synth_batch(B, T, seed0=0)).to(dev)
+    dt, out = timed_forwards(model, x, dev, steps, warmup)
+    rec = {"value": B * T / 8000.0 / dt, "unit": "audio-s/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * dt,
+           "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {seconds:g} s mixtures, bf16 MFMA path"}}
+    if refn0 is not None:
+        got = torch.stack(out, 0)[:, :1].cpu().numpy()
+        mix, s1, s2 = synth_mixture(T, 0)
+        rec["si_sdr_delta_db"] = (permute_si_sdr(got[0, 0], got[1, 0], s1, s2)
+                                  - permute_si_sdr(refn0[0, 0], refn0[1, 0], s1, s2))
+    # the callers' own shape (inference.py / app.py feed one utterance per call), same weights
+    x1 = x[:1].contiguous()
+    dt1, _ = timed_forwards(model, x1, dev, 10, 3)
+    rec["latency_b1_ms"] = 1e3 * dt1
+    return rec
+
+
+class _StubModel:
+    """Stand-in for the separation network in --stub-cpu rehearsals: two scaled copies of the input."""
+    class cfg:
+        num_spks, dim, num_layers = 2, 512, 24
+
+        @staticmethod
+        def flops(T):
+            return 0.0
+
+    def __call__(self, x):
+        return [0.5 * x, -0.5 * x]
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def run_rank(a):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    stub = a.stub_cpu
+    if stub and os.environ.get("MSF2_BENCH_STUB_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                      # rehearsal of a rank that dies before the rendezvous
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None                                           # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = lambda: torch.cuda.synchronize(dev)                    # noqa: E731
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from speech_separation_amd.config import FULL_8K as cfg
-    from speech_separation_amd.model import MossFormerHIP
-    from speech_separation_amd.synth import make_state_dict, synth_batch, synth_mixture, permute_si_sdr
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B, T = a.batch, int(round(a.seconds * 8000))
-    sd = make_state_dict(cfg, 0)
-    from speech_separation_amd import _lib
-    prec = _lib.PREC_BF16 if a.precision == "bf16" else _lib.PREC_FP32
-    model = MossFormerHIP(cfg, compute_device=dev, precision=prec)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model.eval()
-    x = torch.from_numpy(synth_batch(B, T, seed0=rank * B)).to(dev)
+    if stub:
+        model, cfg, sd, prec, lib = _StubModel(), _StubModel.cfg, None, 0, None
+        x = torch.from_numpy(np.random.default_rng(rank).standard_normal((B, T)).astype(np.float32))
+    else:
+        from speech_separation_amd import _lib
+        from speech_separation_amd.config import FULL_8K as cfg
+        from speech_separation_amd.model import MossFormerHIP
+        from speech_separation_amd.synth import make_state_dict, synth_batch
+        lib = _lib.load()
+        sd = make_state_dict(cfg, 0)
+        prec = _lib.PREC_BF16 if a.precision == "bf16" else _lib.PREC_FP32
+        model = MossFormerHIP(cfg, compute_device=dev, precision=prec)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model.eval()
+        x = torch.from_numpy(synth_batch(B, T, seed0=rank * B)).to(dev)
 
-    gathered = [torch.empty((cfg.num_spks, B, T), device=dev) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty((world * cfg.num_spks, B, T), device=dev) if world > 1 else None     # rank-major concatenation
+    collectives = [0]
 
     def step():
         out = torch.stack(model(x), 0)
         if world > 1:
-            dist.all_gather(gathered, out)
+            dist.all_gather_into_tensor(gathered, out)      # every rank ends a step holding all separated waveforms
+            collectives[0] += 1
         return out
+
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            collectives[0] += 1
+        sync()
 
     for _ in range(a.warmup):
         out = step()
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     fence()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dt_mine = time.perf_counter() - t0
+
+    # per-rank times (every rank joins), the job's time is the slowest rank's
+    t = torch.tensor([dt_mine], device=dev, dtype=torch.float64)
+    if world > 1:
+        allt = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, t)
+        collectives[0] += 1
+        per_rank = [float(v) for v in allt.cpu()]
+    else:
+        per_rank = [dt_mine]
+    dt = max(per_rank)
+
+    # the same step with the host copies the callers pay for (waveforms host -> device, separated waveforms
+    # device -> host, pinned buffers); no collective in here
+    e2e_steps = max(1, min(a.steps, 5))
+    if stub:
+        e2e_mine = dt_mine / a.steps
+    else:
+        xh = x.cpu().pin_memory()
+        oh = torch.empty((cfg.num_spks, B, T), dtype=torch.float32).pin_memory()
+        xd = torch.empty_like(x)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(e2e_steps):
+            xd.copy_(xh, non_blocking=True)
+            oh.copy_(torch.stack(model(xd), 0), non_blocking=True)
+        sync()
+        e2e_mine = (time.perf_counter() - t0) / e2e_steps
+    t = torch.tensor([e2e_mine], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        collectives[0] += 1
+    e2e = float(t.item())
 
-    audio_s = world * B * T / 8000.0 * a.steps
+    audio_s_step = world * B * T / 8000.0
     res = {
         "metric": "audio-sec separated/sec (8 kHz)",
-        "value": audio_s / dt,
+        "value": audio_s_step * a.steps / dt,
         "unit": "audio-s/s",
         "n_gpus": world,
         "steps": a.steps,
@@ -167,18 +298,29 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if prec == _lib.PREC_FP32 else "bf16",
+        "dtype": "f32" if prec == 0 else "bf16",
         "data": "synthetic",
         "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {a.seconds:g} s Libri2Mix-min-shaped 8 kHz mixtures, "
                                f"{a.precision}, random-init weights (seeded recipe)",
                    "batch_per_gpu": B, "samples": T, "layers": cfg.num_layers, "dim": cfg.dim,
                    "parallelism": f"utterance-sharded x{world}"},
+        "world_size_seen": dist.get_world_size() if world > 1 else 1,
+        "backend": (dist.get_backend() if world > 1 else None),
+        "ms_per_step_per_rank": [1e3 * v / a.steps for v in per_rank],
+        # inputs resident in HBM ("value") vs. host waveforms in, host waveforms out
+        "value_incl_host_copies": audio_s_step / e2e,
+        "ms_per_step_incl_host_copies": 1e3 * e2e,
         "model_tflops_per_s": world * B * cfg.flops(T) * a.steps / dt / 1e12,
     }
+    if stub:
+        res["stub"] = True
+        res["collectives_per_rank"] = collectives[0]
 
-    if rank == 0:
-        ms, flops, nl = dominant_kernel_probe(model, step, B, T)
-        traffic = measured_traffic(a.precision, B, T)
+    if rank == 0 and not stub:
+        from speech_separation_amd import _lib
+        from speech_separation_amd.synth import synth_batch, synth_mixture, permute_si_sdr
+        ms, flops, nl = dominant_kernel_probe(model, lambda: model(x), B, T)
+        traffic = measured_traffic(a.precision, B, T, lib.msf2_version())
         if prec == _lib.PREC_FP32:
             peak = 157.3
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
@@ -196,32 +338,57 @@ def main():
                                "tflops": flops / (ms * 1e-3) / 1e12}
         if not a.no_cpu_baseline and world == 1:
             from oracle import cpu_ref           # the CPU port that is timed, never the product path
-            cores = min(os.cpu_count() or 1, 16)
-            torch.set_num_threads(cores)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            want = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(avail, 16)
+            torch.set_num_threads(max(1, min(want, avail)))
+            cores = torch.get_num_threads()
             W = cpu_ref.to_torch(sd)
             xs = torch.from_numpy(synth_batch(1, T, seed0=0))
+            times = []
             with torch.no_grad():
-                c0 = time.perf_counter()
-                ref = cpu_ref.forward(W, xs, cfg)
-                cdt = time.perf_counter() - c0
+                for i in range(4):               # one warm-up pass, then the median of three
+                    c0 = time.perf_counter()
+                    ref = cpu_ref.forward(W, xs, cfg)
+                    times.append(time.perf_counter() - c0)
+            cdt = sorted(times[1:])[1]
             got = out[:, :1].cpu().numpy()       # utterance 0 of the last timed step (same seed as the CPU sample)
             refn = torch.stack(ref, 0).numpy()
             mix, s1, s2 = synth_mixture(T, 0)
             sdr_cpu = permute_si_sdr(refn[0, 0], refn[1, 0], s1, s2)
             sdr_gpu = permute_si_sdr(got[0, 0], got[1, 0], s1, s2)
             res["cpu_baseline"] = {"value": (T / 8000.0) / cdt, "unit": "audio-s/s", "cores": cores, "kind": "port",
-                                   "sample": f"one {a.seconds:g} s mixture (batch 1), fp32, one pass, oracle/cpu_ref.py"}
+                                   "sample": f"one {a.seconds:g} s mixture (batch 1), fp32, oracle/cpu_ref.py on {cores} "
+                                             f"threads ({avail} CPUs available to the process): median of 3 passes after 1 warm-up",
+                                   "pass_s": times}
             res["max_abs_err_vs_cpu"] = float(np.abs(got - refn).max())
             res["si_sdr_delta_db"] = sdr_gpu - sdr_cpu
+        if world == 1 and not a.no_secondary:
+            # the callers' own shape: one utterance per call (inference.py:35-41, app.py:269)
+            dt1, _ = timed_forwards(model, x[:1].contiguous(), dev, 10, 3)
+            res["latency"] = {"workload": f"batch 1 x {a.seconds:g} s, {a.precision}", "ms": 1e3 * dt1,
+                              "audio_s_per_s": (T / 8000.0) / dt1}
         if world == 1 and prec == _lib.PREC_FP32 and not a.no_secondary:
             # the bf16 MFMA configuration (batch 64 of the same mixtures), measured the same way, as a second record
             refn0 = refn if "cpu_baseline" in res else None
             del model
             torch.cuda.empty_cache()
             res["secondary"] = secondary_bf16(cfg, sd, dev, T, a.seconds, refn0)
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, argv))
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,58 @@
+"""bench.py started plainly with --gpus N launches its own ranks.  Rehearsed here without a GPU:
+gloo backend, CPU tensors and a stand-in model (--stub-cpu); what is checked is the launching, that
+every rank joins the same collectives, and the single JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(extra_env=None, gpus=2, steps=3, warmup=1):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", str(steps), "--warmup", str(warmup),
+                           "--batch", "2", "--seconds", "0.5", "--stub-cpu"],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_plain_invocation_spawns_ranks_and_prints_one_line():
+    r = _run()
+    assert r.returncode == 0, r.stderr
+    # (gloo itself prints a "[Gloo] Rank 0 is connected ..." notice on stdout; RCCL does not)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and rec["backend"] == "gloo"
+    assert rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert len(rec["ms_per_step_per_rank"]) == 2
+    assert rec["ms_per_step"] == max(rec["ms_per_step_per_rank"])
+    # warm-up + timed steps (one gather each), two fences, the gather of rank times, the max of the
+    # end-to-end times: the same count on every rank or the run would have hung
+    assert rec["collectives_per_rank"] == (1 + 3) + 2 + 1 + 1
+    assert rec["value"] > 0 and rec["value_incl_host_copies"] > 0
+
+
+def test_single_rank_needs_no_launcher():
+    r = _run(gpus=1)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip())
+    assert rec["n_gpus"] == 1 and rec["world_size_seen"] == 1 and rec["collectives_per_rank"] == 0
+
+
+def test_failed_rank_fails_the_launch():
+    r = _run({"MSF2_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr
+    assert "{" not in r.stdout
+
+
+def test_under_an_external_launcher_env_is_respected():
+    """torch.distributed.run sets WORLD_SIZE itself: bench.py must then be a rank, not a launcher."""
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}
+    r = _run(env, gpus=1)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip())["n_gpus"] == 1
