@@ -142,9 +142,17 @@ int msf2_sizeof(int which);
  * msf2_timing_begin and msf2_timing_end every launch of the dominant kernel -- the
  * pointwise contraction of a TCN block -- is bracketed by HIP events on the stream it
  * is launched on; msf2_timing_end waits for them and returns their summed duration
- * and count.  One thread at a time; keep it off inside a timed region. */
+ * and count.  The timer belongs to the thread that called msf2_timing_begin; launches made by other
+ * threads meanwhile are not recorded.  Keep it off inside a timed region. */
 int msf2_timing_begin(void);
 int msf2_timing_end(double* total_ms, int* launches);
+
+/* Test aid with no counterpart in the reference: overrides, for the CALLING THREAD only, which of the equivalent
+ * kernel geometries the bf16 projections use (every choice performs the same arithmetic in the same order, so
+ * results must be bit-identical; the parity tests check exactly that).  name: "ncol_loop", "big_maxn", "no_big",
+ * "geom2" (integers as text) or "geom3", "geom4" (letters naming projections).  name == NULL restores the
+ * defaults.  The library reads no environment variable. */
+int msf2_debug_kernel_choice(const char* name, const char* value);
 
 /* Frames produced by the encoder for T samples: (T - 16) / 8 + 1. */
 int msf2_num_frames(int T);

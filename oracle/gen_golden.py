@@ -144,15 +144,46 @@ def write_fsmn_fixture(out_dir):
 
 
 
+def write_longform_fixtures(out_dir, names):
+    """One 60-second mixture after the decode padding rule (480000 -> 492000 samples, 61 499 frames,
+    241 groups; reference: utils/decode.py:43-51) through the reference model: the long-sequence
+    path of the linear-attention sum (mossformer2_block.py:318-322) and of every global GroupNorm
+    (:521).  The input is regenerated from its seed by the tests; the outputs are stored every
+    `stride`-th sample (a frame spans 16 samples, so every frame is still observed)."""
+    from speech_separation_amd.config import TINY, SMALL, FULL_8K
+    from speech_separation_amd.synth import synth_batch
+    T = 492000
+    for name in names:
+        cfg, stride = {"tiny": (TINY, 4), "small": (SMALL, 4), "full": (FULL_8K, 8)}[name]
+        model = build_reference(cfg)[0]
+        x = synth_batch(1, T, seed0=3)
+        with torch.no_grad():
+            out = model(torch.from_numpy(x))
+        o = np.stack([v.numpy() for v in out], 0)
+        assert o.shape == (cfg.num_spks, 1, T)
+        d = {"seed0": np.int64(3), "T": np.int64(T), "stride": np.int64(stride), "out_strided": o[:, :, ::stride].copy(),
+             "out_peak": np.float32(np.abs(o).max()), "out_rms": np.float32(np.sqrt((o.astype(np.float64) ** 2).mean())),
+             "input_head": x[:, :64].copy()}
+        f = os.path.join(out_dir, f"long_{name}_B1_T{T}.npz")
+        np.savez_compressed(f, **d)
+        print("wrote", f, d["out_strided"].shape, "peak", float(d["out_peak"]), "rms", float(d["out_rms"]), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--full", action="store_true", help="also run the 24-layer 512-dim model (minutes)")
     ap.add_argument("--only-fsmn", action="store_true", help="write only the FSMN-block fixture")
+    ap.add_argument("--longform", default="", help="write only the 60-second fixtures of these configurations "
+                                                   "(comma separated: tiny,small,full; full takes tens of minutes)")
+    ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     install_shims()
-    torch.set_num_threads(8)
+    torch.set_num_threads(a.threads)
+    if a.longform:
+        write_longform_fixtures(a.out, a.longform.split(","))
+        return
     if a.only_fsmn:
         sys.path.insert(0, REF)
         write_fsmn_fixture(a.out)

@@ -66,6 +66,7 @@ SYMBOLS = {
     "msf2_sizeof": (_i, [_i]),
     "msf2_timing_begin": (_i, []),
     "msf2_timing_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "msf2_debug_kernel_choice": (_i, [C.c_char_p, C.c_char_p]),
     "msf2_num_frames": (_i, [_i]),
     "msf2_workspace_bytes": (_sz, [C.POINTER(Config), _i, _i]),
     "msf2_forward": (_i, [C.POINTER(Config), C.POINTER(Weights), _vp, _vp, _i, _i, _vp, _sz, C.POINTER(Taps), _vp]),

@@ -9,16 +9,30 @@ prefix) and shape match; others are reported and left at their current value.
 Problems are printed, not raised, as in the reference.
 """
 import os
+import pickle
 
 import torch
 
 
-def load_checkpoint(checkpoint_path, use_cuda):
+def load_checkpoint(checkpoint_path, use_cuda, trust=None):
+    """Reads the checkpoint with the loader that executes nothing from the file
+    (``weights_only=True``): tensors, containers and numbers, which is what the
+    reference's trainer writes (reference: solver.py:222-252).  A file that
+    loader refuses is NOT unpickled unless the caller opts in -- ``trust=True``
+    or ``MSF2_TRUST_CHECKPOINT=1`` in the environment -- because unpickling runs
+    code from the file (the reference itself always unpickles,
+    utils/misc.py:48-51)."""
     print("Inferencing - Using GPU" if use_cuda else "Inferencing - Using CPU")
+    if trust is None:
+        trust = os.environ.get("MSF2_TRUST_CHECKPOINT") == "1"
     try:
         return torch.load(checkpoint_path, map_location="cpu", weights_only=True)
-    except Exception as e:  # training checkpoints carry optimizer / RNG state that is not plain tensors
-        print(f"safe load refused {checkpoint_path} ({type(e).__name__}); loading it as a trusted training checkpoint")
+    except pickle.UnpicklingError as e:
+        if not trust:
+            print(f"safe load refused {checkpoint_path}: {e}\n"
+                  "set MSF2_TRUST_CHECKPOINT=1 (or trust=True) to unpickle a checkpoint you trust")
+            raise
+        print(f"safe load refused {checkpoint_path}; unpickling it as a trusted checkpoint")
         return torch.load(checkpoint_path, map_location="cpu", weights_only=False)
 
 

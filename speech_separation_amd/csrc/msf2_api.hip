@@ -1,8 +1,11 @@
 // libmsf2: C-ABI entry points and the host-side launch sequence of the
 // MossFormer2_SS forward pass.  All work is enqueued on the caller's stream;
 // nothing here allocates, synchronises or keeps mutable global state -- except the
-// opt-in kernel timer below (off by default, a measurement aid for one thread).
+// opt-in kernel timer below (off by default, a measurement aid owned by one thread at a time).
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include "msf2_common.h"
 #include "msf2_gemm.h"
@@ -18,18 +21,24 @@ thread_local bool g_bad_operand = false;
 // contraction (the kernel that dominates the forward pass) is bracketed by a pair of HIP events
 // recorded on the stream it is launched on, so its duration is measured where it runs, on the
 // data it runs on.  Events cost a few microseconds each: never leave it on in a timed region.
+// The timer belongs to the thread that called msf2_timing_begin(): launches made by other threads (a threaded
+// server shares one library) are not recorded, and the event list is only touched under the mutex.
 struct KernelTimer {
-    bool on = false;
+    std::mutex mu;
+    std::atomic<bool> on{false};
+    std::thread::id owner;
     std::vector<hipEvent_t> ev;
 };
 static KernelTimer g_timer;
 struct TimedLaunch {
     hipStream_t st;
     bool on;
-    TimedLaunch(hipStream_t s, bool wanted) : st(s), on(wanted && g_timer.on && g_timer.ev.size() < 8192) { mark(); }
+    TimedLaunch(hipStream_t s, bool wanted) : st(s), on(wanted && g_timer.on.load(std::memory_order_relaxed)) { mark(); }
     ~TimedLaunch() { mark(); }
     void mark() {
         if (!on) return;
+        std::lock_guard<std::mutex> lk(g_timer.mu);
+        if (!g_timer.on.load() || g_timer.owner != std::this_thread::get_id() || g_timer.ev.size() >= 8192) { on = false; return; }
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
         hipEventRecord(e, st);
@@ -45,32 +54,24 @@ static inline bool fits32(long rows, long ld) { return rows * ld * 4 < (1L << 32
 constexpr int ENC_TS = 32;    // frames per block in the encoder / TCN stage A kernels
 constexpr int TCN_TS = 32;
 
-// Diagnostic kernel-choice switches, read from the environment once per API call (none changes results).
+// Diagnostic kernel-choice switches (none changes results).  The defaults below are what the product runs with; a
+// test can override them for the calling thread through msf2_debug_kernel_choice().  Nothing is read from the environment.
 struct Knobs {
-    int ncol_loop = 2;          // MSF2_NCOL_LOOP: column tiles per workgroup of the 128 x 128 stream form
-    int big_maxn = 4096;        // MSF2_BIG_MAXN: widest projection that may leave that form
-    bool no_big = false;        // MSF2_NO_BIG: 128 x 128 stream form only
-    int geom2 = -1;             // MSF2_GEOM2: 0 / 1 forces the 128 x 256 geometry off / on
-    char g3[16] = "a";          // MSF2_GEOM3 / MSF2_GEOM4: projections that take the 3- / 4-workgroup geometries,
+    int ncol_loop = 2;          // "ncol_loop": column tiles per workgroup of the 128 x 128 stream form
+    int big_maxn = 4096;        // "big_maxn": widest projection that may leave that form
+    bool no_big = false;        // "no_big": 128 x 128 stream form only
+    int geom2 = -1;             // "geom2": 0 / 1 forces the 128 x 256 geometry off / on
+    char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
 };
-static Knobs read_knobs() {
-    Knobs k;
-    if (const char* e = getenv("MSF2_NCOL_LOOP")) k.ncol_loop = atoi(e) > 0 ? atoi(e) : 1;
-    if (const char* e = getenv("MSF2_BIG_MAXN")) k.big_maxn = atoi(e);
-    k.no_big = getenv("MSF2_NO_BIG") != nullptr;
-    if (const char* e = getenv("MSF2_GEOM2")) k.geom2 = atoi(e);
-    if (const char* e = getenv("MSF2_GEOM3")) { strncpy(k.g3, e, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }
-    if (const char* e = getenv("MSF2_GEOM4")) { strncpy(k.g4, e, sizeof(k.g4) - 1); k.g4[sizeof(k.g4) - 1] = 0; }
-    return k;
-}
+static thread_local Knobs g_knobs;
 
 struct Ctx {
     hipStream_t st;
     int B, S, T;
     long M;
     int prec = MSF2_PREC_FP32;
-    Knobs k = read_knobs();
+    Knobs k = g_knobs;
 };
 
 // launch the fp32 or the bf16 build of a contraction
@@ -119,7 +120,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             // 128 x 128 tiles with a short ring, three or four workgroups per CU: more waves to cover the copy latency than
             // the large tiles have.  Measured at 64 x 4 s: the N = 2176 projection 7 % faster with three per CU (four spill
             // there), the plain N = 512 projections 12 % faster with four; the others equal or slower.
-            // MSF2_GEOM3 / MSF2_GEOM4 name the kernels that take them ('a' + EPI for token-shifted A, '0' + EPI otherwise).
+            // the "geom3" / "geom4" choices name the kernels that take them ('a' + EPI for token-shifted A, '0' + EPI otherwise).
             const char* g3 = c.k.g3;
             const char* g4 = c.k.g4;
             const char key = (AMODE ? 'a' : '0') + EPI;
@@ -498,27 +499,46 @@ int msf2_sizeof(int which) {
     }
 }
 int msf2_timing_begin(void) {
+    std::lock_guard<std::mutex> lk(g_timer.mu);
     for (hipEvent_t e : g_timer.ev) hipEventDestroy(e);
     g_timer.ev.clear();
-    g_timer.on = true;
+    g_timer.owner = std::this_thread::get_id();
+    g_timer.on.store(true);
     return MSF2_OK;
 }
 int msf2_timing_end(double* total_ms, int* launches) {
-    g_timer.on = false;
+    std::vector<hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> lk(g_timer.mu);
+        g_timer.on.store(false);
+        ev.swap(g_timer.ev);
+    }
     double sum = 0.0;
     int n = 0, rc = MSF2_OK;
-    for (size_t i = 0; i + 1 < g_timer.ev.size(); i += 2) {
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
         float ms = 0.f;
-        if (hipEventSynchronize(g_timer.ev[i + 1]) != hipSuccess ||
-            hipEventElapsedTime(&ms, g_timer.ev[i], g_timer.ev[i + 1]) != hipSuccess) { rc = MSF2_ERR_LAUNCH; break; }
+        if (hipEventSynchronize(ev[i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) { rc = MSF2_ERR_LAUNCH; break; }
         sum += ms;
         ++n;
     }
-    for (hipEvent_t e : g_timer.ev) hipEventDestroy(e);
-    g_timer.ev.clear();
+    for (hipEvent_t e : ev) hipEventDestroy(e);
     if (total_ms) *total_ms = sum;
     if (launches) *launches = n;
     return rc;
+}
+int msf2_debug_kernel_choice(const char* name, const char* value) {
+    if (!name) { g_knobs = Knobs(); return MSF2_OK; }
+    if (!value) return MSF2_ERR_ARG;
+    Knobs& k = g_knobs;
+    if (!strcmp(name, "ncol_loop")) k.ncol_loop = atoi(value) > 0 ? atoi(value) : 1;
+    else if (!strcmp(name, "big_maxn")) k.big_maxn = atoi(value);
+    else if (!strcmp(name, "no_big")) k.no_big = atoi(value) != 0;
+    else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
+    else if (!strcmp(name, "geom3")) { strncpy(k.g3, value, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }
+    else if (!strcmp(name, "geom4")) { strncpy(k.g4, value, sizeof(k.g4) - 1); k.g4[sizeof(k.g4) - 1] = 0; }
+    else return MSF2_ERR_ARG;
+    return MSF2_OK;
 }
 int msf2_num_frames(int T) { return T < 16 ? 0 : (T - 16) / 8 + 1; }
 

@@ -19,7 +19,12 @@ import torch
 import torch.distributed as dist
 
 
-def make_work_items(lengths, max_batch, max_samples=None):
+# One call of the forward addresses its widest activation ([B * frames, 4 * 512 + 128] fp32) with 32-bit byte
+# offsets, which caps a batch at about 3.9 M samples for the 512-channel model; batches are split to stay below it.
+LIBRARY_MAX_SAMPLES = 3_800_000
+
+
+def make_work_items(lengths, max_batch, max_samples=LIBRARY_MAX_SAMPLES):
     """Group utterance indices by exact length, split groups into batches of at
     most max_batch utterances (and, if given, at most max_samples samples in
     total, but never fewer than one utterance).  Returns [(length, [indices])],
@@ -50,7 +55,7 @@ def assign_items(items, world):
 
 
 def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device="cpu",
-                     references=None, gather=True, max_samples=None):
+                     references=None, gather=True, max_samples=LIBRARY_MAX_SAMPLES):
     """Separate a list of 1-D float32 utterances, sharded over ``world`` ranks.
 
     model_fn(x[B, T] tensor on device) -> list of num_spks tensors [B, T].

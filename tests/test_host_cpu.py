@@ -210,3 +210,69 @@ def test_find_inputs(tmp_path):
     lst = tmp_path / "list.scp"
     lst.write_text(f"{d / 'a.wav'} extra\n\n{d / 'b.wav'}\n")
     assert find_inputs(str(lst)) == [str(d / "a.wav"), str(d / "b.wav")]
+
+
+def test_overlay_import_paths_and_reload(tmp_path):
+    """`dropin/` in front of sys.path gives the reference's import paths (reference: inference.py:4-8,
+    networks.py:9-18): the factory builds the HIP-backed module, reload_for_eval fills it."""
+    import sys
+    saved_path = list(sys.path)
+    saved_mods = set(sys.modules)
+    sys.path[:0] = [os.path.join(ROOT, "dropin"), ROOT]
+    try:
+        from networks import network_wrapper
+        from utils.decode import decode_one_audio as overlay_decode
+        from utils.misc import reload_for_eval as overlay_reload
+        from models.mossformer2.mossformer2 import MossFormer2_SS as OverlaySS
+        assert overlay_decode is decode_one_audio and overlay_reload is reload_for_eval and OverlaySS is MossFormer2_SS
+        model = network_wrapper(Args()).ss_network
+        assert isinstance(model, MossFormerHIP)
+        sd = {k: torch.from_numpy(v) for k, v in make_state_dict(TINY, 5).items()}
+        torch.save({"model": sd}, tmp_path / "m.pt")
+        (tmp_path / "last_checkpoint").write_text("m.pt\n")
+        overlay_reload(model, str(tmp_path), 0)
+        model.eval()
+        got = model.state_dict()
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+        a = Args()
+        a.network = "FRCRN_SE_16K"
+        assert not hasattr(network_wrapper(a), "ss_network")
+    finally:
+        sys.path[:] = saved_path
+        for k in list(sys.modules):
+            if k not in saved_mods and k.split(".")[0] in ("networks", "utils", "models"):
+                del sys.modules[k]
+
+
+class _Odd:               # not a tensor / container / number: weights_only=True refuses it
+    pass
+
+
+def test_checkpoint_that_needs_unpickling_is_opt_in(tmp_path, monkeypatch):
+    """A checkpoint the safe loader refuses is not unpickled silently."""
+    import pickle
+    from speech_separation_amd.checkpoint import load_checkpoint
+
+    torch.save({"model": {}, "extra": _Odd()}, tmp_path / "odd.pt")
+    monkeypatch.delenv("MSF2_TRUST_CHECKPOINT", raising=False)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint(str(tmp_path / "odd.pt"), 0)
+    ck = load_checkpoint(str(tmp_path / "odd.pt"), 0, trust=True)
+    assert "model" in ck
+    monkeypatch.setenv("MSF2_TRUST_CHECKPOINT", "1")
+    assert "extra" in load_checkpoint(str(tmp_path / "odd.pt"), 0)
+    # what the reference's trainer writes loads with the safe loader
+    torch.save({"model": {"w": torch.zeros(3)}, "optimizer": {"state": {}, "param_groups": [{"lr": 1e-3}]}, "epoch": 3,
+                "step": 100, "best_val_loss": 1.5, "halving": False}, tmp_path / "ok.pt")
+    monkeypatch.delenv("MSF2_TRUST_CHECKPOINT")
+    assert load_checkpoint(str(tmp_path / "ok.pt"), 0)["epoch"] == 3
+
+
+def test_work_items_respect_the_library_batch_limit():
+    from speech_separation_amd.parallel import LIBRARY_MAX_SAMPLES, make_work_items
+    items = make_work_items([120000] * 100, max_batch=128)
+    assert all(n * len(idx) <= LIBRARY_MAX_SAMPLES for n, idx in items)
+    assert sorted(i for _, idx in items for i in idx) == list(range(100))
+    lib = _lib.load()
+    cfg = _lib.Config(512, 24, 16, 2, _lib.PREC_FP32)
+    assert lib.msf2_workspace_bytes(cfg, 31, 120000) > 0          # 31 x 15 s = 3.72 M samples: accepted

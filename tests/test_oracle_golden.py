@@ -51,6 +51,21 @@ def test_forward_matches_reference_outputs(golden_dir):
                 assert e <= 2e-5 * max(1.0, np.abs(z[k]).max()), (f, k, e)
 
 
+def test_long_form_matches_reference(golden_dir):
+    """One 60-second mixture (492000 samples after the decode padding rule, 61 499 frames, 241 groups) on the
+    tiny configuration: the oracle against the reference's own output, stored every 4th sample."""
+    from speech_separation_amd.synth import synth_batch
+    z = np.load(os.path.join(golden_dir, "long_tiny_B1_T492000.npz"))
+    T, stride = int(z["T"]), int(z["stride"])
+    x = synth_batch(1, T, seed0=int(z["seed0"]))
+    assert np.array_equal(x[:, :64], z["input_head"])
+    with torch.no_grad():
+        out = cpu_ref.forward(weights("tiny"), torch.from_numpy(x), TINY)
+    got = np.stack([o.numpy() for o in out], 0)[:, :, ::stride]
+    assert got.shape == z["out_strided"].shape
+    assert np.abs(got - z["out_strided"]).max() <= 1e-6
+
+
 @pytest.mark.slow
 def test_full_model_matches_reference(golden_dir):
     f = os.path.join(golden_dir, "fwd_full_B1_T32000.npz")
