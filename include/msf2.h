@@ -283,6 +283,22 @@ int msf2_pit_si_snr(const float* est, const float* src, float* si_snr, float* be
                     void* workspace, size_t workspace_bytes, void* stream);
 size_t msf2_pit_si_snr_ws_bytes(int B, int T);
 
+/*
+ * msf2_pit_si_snr for callers that cannot allocate.  No counterpart in the reference: it exists for code
+ * under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same inputs, outputs
+ * and results as msf2_pit_si_snr, but the partial moments go to a fixed array in device memory that the
+ * library holds on every GPU it runs on until the process ends (MSF2_PIT_NOALLOC_MAX_BLOCKS * 96 bytes =
+ * 768 KiB), so the call takes no workspace and performs no allocation of any kind.
+ *   limit : B * ceil(T / 8192) <= MSF2_PIT_NOALLOC_MAX_BLOCKS, else MSF2_ERR_WORKSPACE (nothing is launched);
+ *   the array is shared by all calls on one GPU: calls that overlap on the same GPU (two streams, two host
+ *   threads) race on it -- serialise them, or use msf2_pit_si_snr with a workspace per call;
+ *   the first call on a device looks up the array's device address (no allocation); make that call outside
+ *   a graph capture.
+ */
+#define MSF2_PIT_NOALLOC_MAX_BLOCKS 8192
+int msf2_pit_si_snr_noalloc(const float* est, const float* src, float* si_snr, float* best, int* perm, int B, int T,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

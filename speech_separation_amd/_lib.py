@@ -85,6 +85,7 @@ SYMBOLS = {
     "msf2_gated_fsmn": (_i, [_vp, C.POINTER(FsmnWeights), _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "msf2_pit_si_snr_ws_bytes": (_sz, [_i, _i]),
     "msf2_pit_si_snr": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "msf2_pit_si_snr_noalloc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "msf2_decoder": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

@@ -857,6 +857,48 @@ int msf2_pit_si_snr(const float* est, const float* src, float* si_snr, float* be
     return check_launch();
 }
 
+// ---- the same statistic for callers that cannot allocate ----------------------
+// The partial moments go to a fixed array in device memory instead of a caller-owned workspace.  Every GPU holds
+// its own copy of the array at its own address; the address is looked up once per device (hipGetSymbolAddress)
+// and only that pointer is ever handed to kernels -- the array's name is a host-side handle, not a device address.
+static __device__ __align__(256) double scratch[(size_t)MSF2_PIT_NOALLOC_MAX_BLOCKS * 12];
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static double* g_scratch_ptr[MAX_DEVICES] = {};
+
+static int scratch_for_current_device(double** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return MSF2_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        double* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            g_last_hip_error = (int)e;
+            return MSF2_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MSF2_OK;
+}
+
+int msf2_pit_si_snr_noalloc(const float* est, const float* src, float* si_snr, float* best, int* perm, int B, int T,
+                            void* stream) {
+    if (!est || !src || (!si_snr && !best && !perm) || B < 1 || T < 2) return MSF2_ERR_ARG;
+    const int nblk = cdiv(T, PIT_CHUNK);
+    if ((long)B * nblk > MSF2_PIT_NOALLOC_MAX_BLOCKS) return MSF2_ERR_WORKSPACE;     // beyond the fixed array
+    double* part = nullptr;
+    const int rc = scratch_for_current_device(&part);
+    if (rc != MSF2_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // every slot the finalize kernel reads ([B][nblk][12]) is written by the moments kernel of the same call, so
+    // nothing of an earlier call's contents survives into this one and nothing needs clearing
+    hipLaunchKernelGGL(pit_moments_kernel, dim3(nblk, B), dim3(256), 0, st, est, src, part, B, T);
+    hipLaunchKernelGGL(pit_finalize_kernel, dim3(B), dim3(64), 0, st, (const double*)part, nblk, T, si_snr, best, perm);
+    return check_launch();
+}
+
 size_t msf2_decoder_ws_bytes(int B, int S) { return align_up((size_t)B * S * 16 * sizeof(float)); }
 
 int msf2_decoder(const float* sep, const float* dec_w, float* est, int B, int S, int C, int T, void* ws, size_t ws_bytes,

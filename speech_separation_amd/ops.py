@@ -135,6 +135,15 @@ def pit_si_snr(est, src):
     return si, best, perm
 
 
+def pit_si_snr_noalloc(est, src, si, best, perm):
+    """pit_si_snr for callers that cannot allocate: every buffer, outputs included, comes from the caller and the
+    library's partial sums live in its fixed device array (msf2_pit_si_snr_noalloc).  Nothing is allocated here."""
+    lib = _lib.load()
+    _, B, T = est.shape
+    _lib.check(lib.msf2_pit_si_snr_noalloc(est.data_ptr(), src.data_ptr(), si.data_ptr(), best.data_ptr(), perm.data_ptr(),
+                                           B, T, _stream(est)), "msf2_pit_si_snr_noalloc")
+
+
 def gated_fsmn(x, packed):
     """x: [B, S, dim] fp32 on the GPU; packed = packing.pack_fsmn_block(...).  Reference:
     Gated_FSMN_Block_Dilated.forward (mossformer2_block.py:456-463)."""
