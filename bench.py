@@ -41,6 +41,9 @@ def parse_args(argv=None):
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="fp32: exact fp32 MFMA (the headline configuration); bf16: bf16 MFMA operands, fp32 accumulate")
+    ap.add_argument("--recurrent", choices=("tcn", "fsmn"), default="tcn",
+                    help="block after each FLASH layer: tcn = GatedTCNBlock (the reference's live model, the headline); "
+                         "fsmn = Gated_FSMN_Block_Dilated (the upstream architecture's block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra records the default single-GPU fp32 run appends (bf16 batch 64, batch-1 latency)")
@@ -216,9 +219,10 @@ def run_rank(a):
         x = torch.from_numpy(np.random.default_rng(rank).standard_normal((B, T)).astype(np.float32))
     else:
         from speech_separation_amd import _lib
-        from speech_separation_amd.config import FULL_8K as cfg
+        from speech_separation_amd.config import MossFormer2Config
         from speech_separation_amd.model import MossFormerHIP
         from speech_separation_amd.synth import make_state_dict, synth_batch
+        cfg = MossFormer2Config(recurrent=a.recurrent)
         lib = _lib.load()
         sd = make_state_dict(cfg, 0)
         prec = _lib.PREC_BF16 if a.precision == "bf16" else _lib.PREC_FP32
@@ -301,7 +305,8 @@ def run_rank(a):
         "dtype": "f32" if prec == 0 else "bf16",
         "data": "synthetic",
         "config": {"workload": f"MossFormer2_SS_8K batch={B} of synthetic {a.seconds:g} s Libri2Mix-min-shaped 8 kHz mixtures, "
-                               f"{a.precision}, random-init weights (seeded recipe)",
+                               f"{a.precision}, random-init weights (seeded recipe)"
+                               + ("" if a.recurrent == "tcn" else ", Gated_FSMN_Block_Dilated as the recurrent block"),
                    "batch_per_gpu": B, "samples": T, "layers": cfg.num_layers, "dim": cfg.dim,
                    "parallelism": f"utterance-sharded x{world}"},
         "world_size_seen": dist.get_world_size() if world > 1 else 1,
@@ -319,9 +324,14 @@ def run_rank(a):
     if rank == 0 and not stub:
         from speech_separation_amd import _lib
         from speech_separation_amd.synth import synth_batch, synth_mixture, permute_si_sdr
-        ms, flops, nl = dominant_kernel_probe(model, lambda: model(x), B, T)
-        traffic = measured_traffic(a.precision, B, T, lib.msf2_version())
-        if prec == _lib.PREC_FP32:
+        if a.recurrent != "tcn":
+            ms = None                      # no TCN pointwise kernel in this form; the roofline record is the headline's
+        else:
+            ms, flops, nl = dominant_kernel_probe(model, lambda: model(x), B, T)
+            traffic = measured_traffic(a.precision, B, T, lib.msf2_version())
+        if ms is None:
+            pass
+        elif prec == _lib.PREC_FP32:
             peak = 157.3
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<ProjNT<0,5>> (TCN pointwise, fp32 MFMA 32x32x2)",
                                "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -370,7 +380,7 @@ def run_rank(a):
             dt1, _ = timed_forwards(model, x[:1].contiguous(), dev, 10, 3)
             res["latency"] = {"workload": f"batch 1 x {a.seconds:g} s, {a.precision}", "ms": 1e3 * dt1,
                               "audio_s_per_s": (T / 8000.0) / dt1}
-        if world == 1 and prec == _lib.PREC_FP32 and not a.no_secondary:
+        if world == 1 and prec == _lib.PREC_FP32 and not a.no_secondary and a.recurrent == "tcn":
             # the bf16 MFMA configuration (batch 64 of the same mixtures), measured the same way, as a second record
             refn0 = refn if "cpu_baseline" in res else None
             del model

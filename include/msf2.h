@@ -40,6 +40,12 @@ extern "C" {
 #define MSF2_PREC_FP32 0   /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                 */
 #define MSF2_PREC_BF16 1   /* bf16 MFMA operands, fp32 accumulate/statistics/residual  */
 
+/* The recurrent block interleaved with the FLASH layers (the list the reference calls `fsmn`,
+ * mossformer2_block.py:635-643, :652-656). */
+#define MSF2_REC_TCN 0     /* GatedTCNBlock (mossformer2_block.py:534-566): what the reference revision instantiates   */
+#define MSF2_REC_FSMN 1    /* Gated_FSMN_Block_Dilated (mossformer2_block.py:430-463): the FSMN-family block of the
+                              upstream architecture, present in the reference but not instantiated by it              */
+
 /* Model geometry (reference: models/mossformer2/mossformer2.py:742-753). */
 typedef struct msf2_config {
     int32_t dim;         /* encoder_embedding_dim == mossformer_sequence_dim; multiple of 64 */
@@ -47,6 +53,8 @@ typedef struct msf2_config {
     int32_t enc_kernel;  /* encoder_kernel_size (must be 16; stride 8)                        */
     int32_t num_spks;    /* must be 2                                                         */
     int32_t precision;   /* MSF2_PREC_*                                                       */
+    int32_t recurrent;   /* MSF2_REC_*: the block that follows each FLASH layer               */
+    int32_t fsmn_inner;  /* MSF2_REC_FSMN: inner_channels of the block (256 in the reference) */
 } msf2_config;
 
 /*
@@ -71,6 +79,35 @@ typedef struct msf2_tcn_weights {   /* reference: mossformer2_block.py:508-531 (
     const float* c2;       /* [C]                                        */
 } msf2_tcn_weights;
 
+/* Gated_FSMN_Block_Dilated (reference: mossformer2_block.py:430-463), packed by
+ * speech_separation_amd.packing.pack_fsmn_block; see msf2_gated_fsmn below. */
+typedef struct msf2_fsmn_weights {
+    const float* w1;      /* [inner][dim]  conv1.0.weight                      */
+    const float* b1;      /* [inner]                                            */
+    float prelu1;         /* conv1.1.weight (one slope)                         */
+    const float* ln1_g;   /* [inner] norm1                                      */
+    const float* ln1_b;
+    const float* w_uv;    /* [2 inner][inner] to_u | to_v Linear, LayerNorm gain folded in */
+    const float* c1_uv;   /* [2 inner] W beta + bias                            */
+    const float* c2_uv;   /* [2 inner] row sums of the folded weights           */
+    const float* dw_uv;   /* [17][2 inner] ConvModule filters, tap major        */
+    const float* w_lin;   /* [inner][inner] fsmn.linear                         */
+    const float* b_lin;
+    const float* w_proj;  /* [inner][inner] fsmn.project (no bias)              */
+    const float* w_c1;    /* [39][inner]    fsmn.conv.conv1, tap major          */
+    const float* in1_g;   /* [inner] fsmn.conv.norm1 / prelu1                   */
+    const float* in1_b;
+    const float* pr1;
+    const float* w_c2;    /* [39][2][inner] fsmn.conv.conv2, tap major, input-of-group major */
+    const float* in2_g;
+    const float* in2_b;
+    const float* pr2;
+    const float* ln2_g;   /* [inner] norm2                                      */
+    const float* ln2_b;
+    const float* w2;      /* [dim][inner]  conv2.weight                         */
+    const float* b2;      /* [dim]                                              */
+} msf2_fsmn_weights;
+
 typedef struct msf2_layer_weights {
     /* FLASH_ShareA_FFConvM (reference: mossformer2_block.py:171-325) */
     const float* w_hq;     /* [4*dim + 128][dim]  to_hidden | to_qk rows, ScaleNorm gain folded */
@@ -91,6 +128,9 @@ typedef struct msf2_layer_weights {
     const float* w_po;     /* [dim][dim] proj_out                                               */
     const float* b_po;     /* [dim]                                                             */
     msf2_tcn_weights tcn[MSF2_TCN_DEPTH];
+    /* MSF2_REC_FSMN: HOST pointer to the block's weights (the GatedTCNBlock fields above are then unused);
+     * with MSF2_PREC_BF16 its projection matrices (w1, w_uv, w_lin, w_proj, w2) hold bf16 values */
+    const msf2_fsmn_weights* fsmn;
 } msf2_layer_weights;
 
 typedef struct msf2_weights {
@@ -236,34 +276,9 @@ size_t msf2_decoder_ws_bytes(int B, int S);
  * models/mossformer2/layer_norm.py:14-35).  The block is not reachable from MossFormer2_SS in the
  * reference revision this library follows (its layers use GatedTCNBlock), so it is a stand-alone
  * operator: fp32, x and y [B, S, dim], inner = the block's inner_channels (256 in the reference).
- * Weights as packed by speech_separation_amd.packing.pack_fsmn_block:
+ * Weights as packed by speech_separation_amd.packing.pack_fsmn_block (struct msf2_fsmn_weights above).
+ * The same launch sequence runs inside msf2_forward when msf2_config.recurrent == MSF2_REC_FSMN.
  */
-typedef struct msf2_fsmn_weights {
-    const float* w1;      /* [inner][dim]  conv1.0.weight                      */
-    const float* b1;      /* [inner]                                            */
-    float prelu1;         /* conv1.1.weight (one slope)                         */
-    const float* ln1_g;   /* [inner] norm1                                      */
-    const float* ln1_b;
-    const float* w_uv;    /* [2 inner][inner] to_u | to_v Linear, LayerNorm gain folded in */
-    const float* c1_uv;   /* [2 inner] W beta + bias                            */
-    const float* c2_uv;   /* [2 inner] row sums of the folded weights           */
-    const float* dw_uv;   /* [17][2 inner] ConvModule filters, tap major        */
-    const float* w_lin;   /* [inner][inner] fsmn.linear                         */
-    const float* b_lin;
-    const float* w_proj;  /* [inner][inner] fsmn.project (no bias)              */
-    const float* w_c1;    /* [39][inner]    fsmn.conv.conv1, tap major          */
-    const float* in1_g;   /* [inner] fsmn.conv.norm1 / prelu1                   */
-    const float* in1_b;
-    const float* pr1;
-    const float* w_c2;    /* [39][2][inner] fsmn.conv.conv2, tap major, input-of-group major */
-    const float* in2_g;
-    const float* in2_b;
-    const float* pr2;
-    const float* ln2_g;   /* [inner] norm2                                      */
-    const float* ln2_b;
-    const float* w2;      /* [dim][inner]  conv2.weight                         */
-    const float* b2;      /* [dim]                                              */
-} msf2_fsmn_weights;
 int msf2_gated_fsmn(const float* x, const msf2_fsmn_weights* w, float* y, int B, int S, int dim, int inner,
                     void* workspace, size_t workspace_bytes, void* stream);
 size_t msf2_gated_fsmn_ws_bytes(int B, int S, int dim, int inner);

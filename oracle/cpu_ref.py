@@ -177,7 +177,10 @@ def forward(W, mix, cfg, taps=None):
         x = flash_layer(x, W, f"{MDL}.layers.{l}", cfg.group_size)
         if taps is not None and l == 0:
             taps["flash0"] = x
-        x = gated_tcn(x, W, f"{MDL}.fsmn.{l}", cfg.tcn_depth)
+        if getattr(cfg, "recurrent", "tcn") == "fsmn":
+            x = gated_fsmn_block_dilated(x, W, f"{MDL}.fsmn.{l}")
+        else:
+            x = gated_tcn(x, W, f"{MDL}.fsmn.{l}", cfg.tcn_depth)
         if taps is not None and l == 0:
             taps["tcn0"] = x
     # reference: mossformer2.py:350, :500-506

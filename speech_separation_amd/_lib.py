@@ -16,32 +16,15 @@ QK_DIM = 128
 GROUP = 256
 PREC_FP32 = 0
 PREC_BF16 = 1
+REC_TCN = 0      # GatedTCNBlock after each FLASH layer (what the reference revision instantiates)
+REC_FSMN = 1     # Gated_FSMN_Block_Dilated (the upstream architecture's block, present in the reference)
 
 fp = C.POINTER(C.c_float)
 
 
 class Config(C.Structure):
     _fields_ = [("dim", C.c_int32), ("num_layers", C.c_int32), ("enc_kernel", C.c_int32),
-                ("num_spks", C.c_int32), ("precision", C.c_int32)]
-
-
-class TcnWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("dw_w", "dw_b", "w_gate", "b_gate", "w_pw", "c1", "c2")]
-
-
-class LayerWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in (
-        "w_hq", "b_hq", "dw_hq", "os_gamma", "os_beta", "rot_freqs", "w_out", "b_out", "dw_out",
-        "w_gg", "b_gg", "w_in", "c1_in", "c2_in", "w_po", "b_po")] + [("tcn", TcnWeights * TCN_DEPTH)]
-
-
-class Weights(C.Structure):
-    _fields_ = [("enc_w", C.c_void_p), ("w_ce", C.c_void_p), ("c1_ce", C.c_void_p), ("c2_ce", C.c_void_p),
-                ("pe_inv_freq", C.c_void_p), ("pe_scale", C.c_float), ("prelu_a", C.c_float),
-                ("fin_ln_w", C.c_void_p), ("fin_ln_b", C.c_void_p), ("fin_gn_w", C.c_void_p),
-                ("fin_gn_b", C.c_void_p), ("w_co", C.c_void_p), ("b_co", C.c_void_p), ("w_o", C.c_void_p),
-                ("b_o", C.c_void_p), ("w_og", C.c_void_p), ("b_og", C.c_void_p), ("w_cd", C.c_void_p),
-                ("dec_w", C.c_void_p), ("layers", C.POINTER(LayerWeights))]
+                ("num_spks", C.c_int32), ("precision", C.c_int32), ("recurrent", C.c_int32), ("fsmn_inner", C.c_int32)]
 
 
 class FsmnWeights(C.Structure):
@@ -51,6 +34,26 @@ class FsmnWeights(C.Structure):
                 ("in1_g", C.c_void_p), ("in1_b", C.c_void_p), ("pr1", C.c_void_p), ("w_c2", C.c_void_p),
                 ("in2_g", C.c_void_p), ("in2_b", C.c_void_p), ("pr2", C.c_void_p), ("ln2_g", C.c_void_p),
                 ("ln2_b", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p)]
+
+
+class TcnWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dw_w", "dw_b", "w_gate", "b_gate", "w_pw", "c1", "c2")]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "w_hq", "b_hq", "dw_hq", "os_gamma", "os_beta", "rot_freqs", "w_out", "b_out", "dw_out",
+        "w_gg", "b_gg", "w_in", "c1_in", "c2_in", "w_po", "b_po")] + [("tcn", TcnWeights * TCN_DEPTH),
+                                                                           ("fsmn", C.POINTER(FsmnWeights))]
+
+
+class Weights(C.Structure):
+    _fields_ = [("enc_w", C.c_void_p), ("w_ce", C.c_void_p), ("c1_ce", C.c_void_p), ("c2_ce", C.c_void_p),
+                ("pe_inv_freq", C.c_void_p), ("pe_scale", C.c_float), ("prelu_a", C.c_float),
+                ("fin_ln_w", C.c_void_p), ("fin_ln_b", C.c_void_p), ("fin_gn_w", C.c_void_p),
+                ("fin_gn_b", C.c_void_p), ("w_co", C.c_void_p), ("b_co", C.c_void_p), ("w_o", C.c_void_p),
+                ("b_o", C.c_void_p), ("w_og", C.c_void_p), ("b_og", C.c_void_p), ("w_cd", C.c_void_p),
+                ("dec_w", C.c_void_p), ("layers", C.POINTER(LayerWeights))]
 
 
 class Taps(C.Structure):

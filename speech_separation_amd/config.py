@@ -21,6 +21,11 @@ class MossFormer2Config:
     rot_dim: int = 32         # min(32, qk_dim)
     tcn_depth: int = 8
     dw_kernel: int = 17
+    # The block interleaved with the FLASH layers: "tcn" = GatedTCNBlock (what the reference revision builds,
+    # mossformer2_block.py:635-643), "fsmn" = Gated_FSMN_Block_Dilated (:430-463; the upstream architecture's block,
+    # defined in the reference but not instantiated by it), with fsmn_inner inner channels.
+    recurrent: str = "tcn"
+    fsmn_inner: int = 256
 
     @property
     def hidden(self) -> int:      # to_hidden output = v | u
@@ -50,6 +55,9 @@ class MossFormer2Config:
         flash_s = d * h + h * k17 + d * q + q * k17 + q * v2 + q * v2 + self.vdim * d + d * k17
         flash_sp = q * self.group_size + self.group_size * v2
         tcn = 3 * d * d + self.tcn_depth * (3 * d + 2 * d * d)
+        if self.recurrent == "fsmn":       # conv1, to_u | to_v (+ ConvModule), linear, project, the two 39-tap convs, conv2
+            i = self.fsmn_inner
+            tcn = d * i + 2 * i * i + 2 * i * k17 + 2 * i * i + 39 * i + 2 * 39 * i + i * d
         head = d * d + d * d * self.num_spks + 2 * d * d * self.num_spks + d * d * self.num_spks \
             + self.enc_kernel * d + self.enc_kernel * d * self.num_spks
         macs = self.num_layers * ((flash_s + tcn) * S + flash_sp * Sp) + head * S
@@ -64,10 +72,14 @@ class MossFormer2Config:
         return MossFormer2Config(dim=dim,
                                  num_layers=int(args.num_mossformer_layer),
                                  enc_kernel=int(args.encoder_kernel_size),
-                                 num_spks=int(args.num_spks))
+                                 num_spks=int(args.num_spks),
+                                 recurrent=str(getattr(args, "msf2_recurrent", "tcn")),
+                                 fsmn_inner=int(getattr(args, "msf2_fsmn_inner", 256)))
 
 
 FULL_8K = MossFormer2Config()
 # small configurations used by the parity fixtures
 TINY = MossFormer2Config(dim=64, num_layers=2)
 SMALL = MossFormer2Config(dim=128, num_layers=2)
+TINY_FSMN = MossFormer2Config(dim=64, num_layers=2, recurrent="fsmn", fsmn_inner=64)
+SMALL_FSMN = MossFormer2Config(dim=128, num_layers=2, recurrent="fsmn", fsmn_inner=64)

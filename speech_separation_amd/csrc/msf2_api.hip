@@ -408,6 +408,77 @@ static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short*
     }
 }
 
+// ---- FSMN-family block (Gated_FSMN_Block_Dilated) ------------------------------------
+struct FsmnWs {
+    float *c1, *n1, *uv_pre, *uv, *f1, *p1, *t1, *o1, *t2, *seq, *n2, *rowstat, *part, *stats;
+    int ntile;
+};
+static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
+    FsmnWs w;
+    const long M = (long)B * S;
+    w.ntile = cdiv(S, FS_TS);
+    w.c1 = ar.take<float>(M * inner);   w.n1 = ar.take<float>(M * inner);
+    w.uv_pre = ar.take<float>(M * 2 * inner);  w.uv = ar.take<float>(M * 2 * inner);
+    w.f1 = ar.take<float>(M * inner);   w.p1 = ar.take<float>(M * inner);
+    w.t1 = ar.take<float>(M * inner);   w.o1 = ar.take<float>(M * inner);
+    w.t2 = ar.take<float>(M * inner);   w.seq = ar.take<float>(M * inner);
+    w.n2 = ar.take<float>(M * inner);
+    w.rowstat = ar.take<float>(2 * M);
+    w.part = ar.take<float>(2L * B * w.ntile * inner);
+    w.stats = ar.take<float>(2L * B * inner);
+    return w;
+}
+static inline bool fsmn_dims_ok(int dim, int inner) {
+    return dim >= BK && (dim % BK) == 0 && dim <= 1024 && inner >= BK && (inner % BK) == 0 && inner <= 512;
+}
+// y = block(x); y may alias x (the last projection reads its residual and writes its result at the same element).
+// The contractions follow c.prec (bf16 mode: projection matrices bf16, activations rounded on their way into LDS);
+// everything else is fp32.  y16: optional bf16 image of y; sq_part: optional partial row sums of squares of y
+// (see launch_proj); returns their slab width.
+static int run_gated_fsmn(const Ctx& c, const FsmnWs& w, const float* x, const msf2_fsmn_weights* fw, float* y, int dim, int inner,
+                          unsigned short* y16 = nullptr, float* sq_part = nullptr) {
+    const int B = c.B, S = c.S;
+    const long M = c.M;
+    const int C = inner;
+    {   // c1 = PReLU(x W1^T + b1)
+        ProjArgs a = proj_args(x, dim, fw->w1, dim, C, S, w.c1, C);
+        a.bias = fw->b1; a.act = 4; a.prelu = fw->prelu1;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.c1, fw->ln1_g, fw->ln1_b, w.n1, M, C, 1e-5f);
+    launch_rowstat<1>(c, w.n1, C, w.rowstat, C, 0, 1e-5f);
+    {   // [u | v] = silu(LayerNorm(n1) W^T + b), both FFConvM projections in one contraction
+        ProjArgs a = proj_args(w.n1, C, fw->w_uv, C, 2 * C, S, w.uv_pre, 2 * C);
+        a.rowstat = w.rowstat; a.c1 = fw->c1_uv; a.c2 = fw->c2_uv; a.act = 1;
+        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    }
+    launch_dwconv17(c, w.uv_pre, 2 * C, fw->dw_uv, w.uv, 2 * C, 2 * C, 0);
+    {   // f1 = relu(u Wl^T + b)
+        ProjArgs a = proj_args(w.uv, 2 * C, fw->w_lin, C, C, S, w.f1, C);
+        a.bias = fw->b_lin; a.act = 3;
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    {   // p1 = f1 Wp^T
+        ProjArgs a = proj_args(w.f1, C, fw->w_proj, C, C, S, w.p1, C);
+        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+    }
+    const dim3 cgrid(cdiv(C / 4, 64), w.ntile, B), fgrid(cdiv(C, 256), B);
+    const int egrid = cdiv(M * (C / 4), 256);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<1>, cgrid, dim3(64), 0, c.st, w.p1, (const float*)nullptr, fw->w_c1, w.t1, w.part, S, C, 1);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(in_prelu_kernel, dim3(egrid), dim3(256), 0, c.st, w.t1, w.stats, fw->in1_g, fw->in1_b, fw->pr1, w.o1, M, S, C);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<2>, cgrid, dim3(64), 0, c.st, w.o1, w.p1, fw->w_c2, w.t2, w.part, S, C, 2);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(fsmn_gate_kernel, dim3(egrid), dim3(256), 0, c.st, w.uv, w.t2, w.stats, fw->in2_g, fw->in2_b, fw->pr2, w.n1,
+                       w.seq, M, S, C);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f);
+    {   // y = x + n2 W2^T + b2
+        ProjArgs a = proj_args(w.n2, C, fw->w2, C, dim, S, y, dim);
+        a.bias = fw->b2; a.res = x; a.ldr = dim; a.out16 = y16; a.sq_part = sq_part;
+        return launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
+    }
+}
+
 // ---- decoder ----------------------------------------------------------------
 static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, float* fv, float* est, int C) {
     int grid = cdiv(c.M, 4);
@@ -423,7 +494,8 @@ struct FwdWs {
     unsigned short *x16, *o16;           // bf16 mode: operand images of the residual stream and the attention output
     unsigned short *hu_pre16, *hu16;     // bf16 mode: the hidden tensor before / after its ConvModule lives in bf16 only
     AttnWs at;
-    TcnWs tc;
+    TcnWs tc;            // MSF2_REC_TCN
+    FsmnWs fs;           // MSF2_REC_FSMN
     int nblk_enc, nblk_ln;
 };
 static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
@@ -455,7 +527,10 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
         w.o16 = ar.take<unsigned short>(M * E);
     }
     w.at = attn_ws(ar, B, S, E);
-    w.tc = tcn_ws(ar, B, S, C, cfg.precision);
+    w.tc = TcnWs();
+    w.fs = FsmnWs();
+    if (cfg.recurrent == MSF2_REC_FSMN) w.fs = fsmn_ws(ar, B, S, cfg.fsmn_inner);
+    else w.tc = tcn_ws(ar, B, S, C, cfg.precision);
     return w;
 }
 
@@ -463,6 +538,8 @@ static int check_cfg(const msf2_config* cfg) {
     if (!cfg) return MSF2_ERR_ARG;
     if (!dim_ok(cfg->dim) || cfg->num_layers < 0 || cfg->enc_kernel != 16 || cfg->num_spks != 2) return MSF2_ERR_ARG;
     if (cfg->precision != MSF2_PREC_FP32 && cfg->precision != MSF2_PREC_BF16) return MSF2_ERR_ARG;
+    if (cfg->recurrent != MSF2_REC_TCN && cfg->recurrent != MSF2_REC_FSMN) return MSF2_ERR_ARG;
+    if (cfg->recurrent == MSF2_REC_FSMN && !fsmn_dims_ok(cfg->dim, cfg->fsmn_inner)) return MSF2_ERR_ARG;
     return MSF2_OK;
 }
 
@@ -486,7 +563,7 @@ const char* msf2_strerror(int code) {
     }
 }
 int msf2_last_hip_error(void) { return g_last_hip_error; }
-int msf2_version(void) { return 1; }
+int msf2_version(void) { return 2; }
 int msf2_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(msf2_config);
@@ -607,11 +684,17 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
             launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
         }
         // x += po + dwconv17(po), and the LayerNorm statistics of x that the gated TCN block starts with
-        const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, w.tc.rowstat,
+        // (rowstat: the FSMN block has no use for them, but the bf16 form of this kernel always writes them)
+        const bool fsmn = cfg->recurrent == MSF2_REC_FSMN;
+        const bool have_ln = launch_dwconv17(c, w.po, C, lw.dw_out, w.x, C, C, 1, w.x16, fsmn ? (w.x16 ? w.rowstat : nullptr) : w.tc.rowstat,
                                              (w.o16 && C <= 512) ? reinterpret_cast<const unsigned short*>(w.po) : nullptr);
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
-        // ---- GatedTCNBlock ----
-        sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);
+        // ---- the recurrent block: GatedTCNBlock, or Gated_FSMN_Block_Dilated in place on x ----
+        if (fsmn) {
+            if (!lw.fsmn) return MSF2_ERR_ARG;
+            sq_w = run_gated_fsmn(c, w.fs, w.x, lw.fsmn, w.x, C, cfg->fsmn_inner, w.x16, w.sqx);
+        } else
+            sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);
         if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);
     }
 
@@ -765,25 +848,6 @@ int msf2_diag_read2(unsigned long long* host, size_t n) {
 #endif
 
 // ---- FSMN-family block -------------------------------------------------------
-struct FsmnWs {
-    float *c1, *n1, *uv_pre, *uv, *f1, *p1, *t1, *o1, *t2, *seq, *n2, *rowstat, *part, *stats;
-    int ntile;
-};
-static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
-    FsmnWs w;
-    const long M = (long)B * S;
-    w.ntile = cdiv(S, FS_TS);
-    w.c1 = ar.take<float>(M * inner);   w.n1 = ar.take<float>(M * inner);
-    w.uv_pre = ar.take<float>(M * 2 * inner);  w.uv = ar.take<float>(M * 2 * inner);
-    w.f1 = ar.take<float>(M * inner);   w.p1 = ar.take<float>(M * inner);
-    w.t1 = ar.take<float>(M * inner);   w.o1 = ar.take<float>(M * inner);
-    w.t2 = ar.take<float>(M * inner);   w.seq = ar.take<float>(M * inner);
-    w.n2 = ar.take<float>(M * inner);
-    w.rowstat = ar.take<float>(2 * M);
-    w.part = ar.take<float>(2L * B * w.ntile * inner);
-    w.stats = ar.take<float>(2L * B * inner);
-    return w;
-}
 size_t msf2_gated_fsmn_ws_bytes(int B, int S, int dim, int inner) {
     if (B < 1 || S < 1 || dim < BK || inner < BK) return 0;
     Arena ar(nullptr, 0);
@@ -793,51 +857,13 @@ size_t msf2_gated_fsmn_ws_bytes(int B, int S, int dim, int inner) {
 int msf2_gated_fsmn(const float* x, const msf2_fsmn_weights* fw, float* y, int B, int S, int dim, int inner, void* ws,
                     size_t ws_bytes, void* stream) {
     if (!x || !fw || !y || !ws || B < 1 || S < 1) return MSF2_ERR_ARG;
-    if (dim < BK || (dim % BK) || dim > 1024 || inner < BK || (inner % BK) || inner > 512) return MSF2_ERR_ARG;
+    if (!fsmn_dims_ok(dim, inner)) return MSF2_ERR_ARG;
     if (!fits32((long)B * S, 2 * inner > dim ? 2 * inner : dim)) return MSF2_ERR_ARG;
     if (ws_bytes < msf2_gated_fsmn_ws_bytes(B, S, dim, inner)) return MSF2_ERR_WORKSPACE;
     Arena ar(ws, ws_bytes);
     const FsmnWs w = fsmn_ws(ar, B, S, inner);
     Ctx c = {(hipStream_t)stream, B, S, 0, (long)B * S};
-    const long M = c.M;
-    const int C = inner;
-    {   // c1 = PReLU(x W1^T + b1)
-        ProjArgs a = proj_args(x, dim, fw->w1, dim, C, S, w.c1, C);
-        a.bias = fw->b1; a.act = 4; a.prelu = fw->prelu1;
-        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
-    }
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.c1, fw->ln1_g, fw->ln1_b, w.n1, M, C, 1e-5f);
-    launch_rowstat<1>(c, w.n1, C, w.rowstat, C, 0, 1e-5f);
-    {   // [u | v] = silu(LayerNorm(n1) W^T + b), both FFConvM projections in one contraction
-        ProjArgs a = proj_args(w.n1, C, fw->w_uv, C, 2 * C, S, w.uv_pre, 2 * C);
-        a.rowstat = w.rowstat; a.c1 = fw->c1_uv; a.c2 = fw->c2_uv; a.act = 1;
-        launch_proj<A_PLAIN, EPI_NORM>(c, a);
-    }
-    launch_dwconv17(c, w.uv_pre, 2 * C, fw->dw_uv, w.uv, 2 * C, 2 * C, 0);
-    {   // f1 = relu(u Wl^T + b)
-        ProjArgs a = proj_args(w.uv, 2 * C, fw->w_lin, C, C, S, w.f1, C);
-        a.bias = fw->b_lin; a.act = 3;
-        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
-    }
-    {   // p1 = f1 Wp^T
-        ProjArgs a = proj_args(w.f1, C, fw->w_proj, C, C, S, w.p1, C);
-        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
-    }
-    const dim3 cgrid(cdiv(C / 4, 64), w.ntile, B), fgrid(cdiv(C, 256), B);
-    const int egrid = cdiv(M * (C / 4), 256);
-    hipLaunchKernelGGL(fsmn_conv39_kernel<1>, cgrid, dim3(64), 0, c.st, w.p1, (const float*)nullptr, fw->w_c1, w.t1, w.part, S, C, 1);
-    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
-    hipLaunchKernelGGL(in_prelu_kernel, dim3(egrid), dim3(256), 0, c.st, w.t1, w.stats, fw->in1_g, fw->in1_b, fw->pr1, w.o1, M, S, C);
-    hipLaunchKernelGGL(fsmn_conv39_kernel<2>, cgrid, dim3(64), 0, c.st, w.o1, w.p1, fw->w_c2, w.t2, w.part, S, C, 2);
-    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
-    hipLaunchKernelGGL(fsmn_gate_kernel, dim3(egrid), dim3(256), 0, c.st, w.uv, w.t2, w.stats, fw->in2_g, fw->in2_b, fw->pr2, w.n1,
-                       w.seq, M, S, C);
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f);
-    {   // y = x + n2 W2^T + b2
-        ProjArgs a = proj_args(w.n2, C, fw->w2, C, dim, S, y, dim);
-        a.bias = fw->b2; a.res = x; a.ldr = dim;
-        launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
-    }
+    run_gated_fsmn(c, w, x, fw, y, dim, inner);
     return check_launch();
 }
 

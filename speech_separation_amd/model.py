@@ -18,6 +18,14 @@ utils/decode.py:62,73).  ``MossFormerHIP`` offers the same surface:
 The forward is re-entrant: packed weights are read-only and every call takes
 its own workspace from torch's caching allocator (the reference's Flask server
 is threaded and shares one model object, reference: app.py:256-259).
+
+``use_graphs=True`` replays the forward of a given input shape from a captured
+HIP graph (the library call allocates nothing and never synchronises, so the
+whole launch sequence -- about 1 000 kernels -- is capturable).  That is for the
+callers' own shape, one utterance per call (reference: inference.py:35-41,
+app.py:269), where the eager launch sequence is host-bound.  A graph owns its
+input, output and workspace buffers, so replays of one shape are serialised by
+a lock; the outputs returned are copies.
 """
 import threading
 
@@ -49,7 +57,9 @@ def _attach(root: nn.Module, key: str, tensor: torch.Tensor):
 
 
 class MossFormerHIP(nn.Module):
-    def __init__(self, cfg: MossFormer2Config, compute_device=None, precision=_lib.PREC_FP32, init_seed=0):
+    MAX_GRAPHS = 8          # captured shapes kept per model (each holds its own workspace)
+
+    def __init__(self, cfg: MossFormer2Config, compute_device=None, precision=_lib.PREC_FP32, init_seed=0, use_graphs=False):
         super().__init__()
         self.cfg = cfg
         self.num_spks = cfg.num_spks
@@ -62,10 +72,14 @@ class MossFormerHIP(nn.Module):
         self._packed = None
         self._pack_lock = threading.Lock()
         self._lib = None
+        self.use_graphs = bool(use_graphs)
+        self._graphs = {}
+        self._graph_lock = threading.Lock()
 
     # -- weight life-cycle ------------------------------------------------------
     def _invalidate(self):
         self._packed = None
+        self._graphs = {}           # captured graphs hold pointers into the old packed weights
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -111,6 +125,12 @@ class MossFormerHIP(nn.Module):
         B, T = x.shape
         if T < self.cfg.enc_kernel:
             raise ValueError(f"input shorter than the encoder kernel ({T} < {self.cfg.enc_kernel})")
+        if self.use_graphs and taps is None:
+            out = self._forward_graph(pk, x, B, T)
+            outs = [out[s] for s in range(self.num_spks)]
+            if src_device != dev or src_dtype != torch.float32:
+                outs = [o.to(device=src_device, dtype=src_dtype) for o in outs]
+            return outs
         with torch.cuda.device(dev):
             xin = x.detach().to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
             out = torch.empty((self.num_spks, B, T), device=dev, dtype=torch.float32)
@@ -140,6 +160,40 @@ class MossFormerHIP(nn.Module):
         return outs
 
 
+    def _forward_graph(self, pk, x, B, T):
+        lib, dev = self._lib, pk.device
+        with self._graph_lock, torch.cuda.device(dev):
+            ent = self._graphs.get((B, T))
+            if ent is None:
+                nbytes = lib.msf2_workspace_bytes(pk.c_cfg, B, T)
+                if nbytes == 0:
+                    raise _lib.Msf2Error("msf2_workspace_bytes rejected the configuration")
+                if len(self._graphs) >= self.MAX_GRAPHS:
+                    self._graphs.pop(next(iter(self._graphs)))
+                xin = torch.zeros((B, T), device=dev, dtype=torch.float32)
+                out = torch.empty((self.num_spks, B, T), device=dev, dtype=torch.float32)
+                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    # one eager pass first: a launch failure surfaces here, not inside the capture
+                    _lib.check(lib.msf2_forward(pk.c_cfg, pk.struct, xin.data_ptr(), out.data_ptr(), B, T,
+                                                ws.data_ptr(), nbytes, None, side.cuda_stream), "msf2_forward")
+                    side.synchronize()
+                    with torch.cuda.graph(graph, stream=side):
+                        rc = lib.msf2_forward(pk.c_cfg, pk.struct, xin.data_ptr(), out.data_ptr(), B, T,
+                                              ws.data_ptr(), nbytes, None, torch.cuda.current_stream(dev).cuda_stream)
+                    _lib.check(rc, "msf2_forward (graph capture)")
+                torch.cuda.current_stream(dev).wait_stream(side)
+                ent = (graph, xin, out, ws)
+                self._graphs[(B, T)] = ent
+            graph, xin, out, _ = ent
+            xin.copy_(x.detach().to(dtype=torch.float32), non_blocking=True)
+            graph.replay()
+            return out.clone()
+
+
 class MossFormer2_SS(nn.Module):
     """Model wrapper with the reference's constructor contract: reads the
     hyper-parameters off ``args`` and exposes the network as ``.model``
@@ -148,7 +202,8 @@ class MossFormer2_SS(nn.Module):
     def __init__(self, args):
         super().__init__()
         self.model = MossFormerHIP(MossFormer2Config.from_args(args),
-                                   precision=int(getattr(args, "msf2_precision", _lib.PREC_FP32)))
+                                   precision=int(getattr(args, "msf2_precision", _lib.PREC_FP32)),
+                                   use_graphs=bool(getattr(args, "msf2_use_graphs", False)))
 
     def forward(self, x):
         return self.model(x)

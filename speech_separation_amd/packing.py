@@ -55,6 +55,8 @@ class PackedWeights:
             return devw(Wg), dev(c1), dev(c2)
 
         self.layers = (_lib.LayerWeights * max(cfg.num_layers, 1))()
+        fsmn = cfg.recurrent == "fsmn"
+        self.fsmn_blocks = (_lib.FsmnWeights * max(cfg.num_layers, 1))()
         for i in range(cfg.num_layers):
             lw = self.layers[i]
             p = f"{MDL}.layers.{i}"
@@ -72,6 +74,13 @@ class PackedWeights:
             lw.b_out = dev(g(f"{p}.to_out.mdl.1.bias"))
             lw.dw_out = dev(g(f"{p}.to_out.mdl.3.sequential.1.conv.weight")[:, 0, :].t())
             q = f"{MDL}.fsmn.{i}"
+            if fsmn:
+                blk, _, inner, keep = pack_fsmn_block(state, self.device, q, precision)
+                assert inner == cfg.fsmn_inner, (inner, cfg.fsmn_inner)
+                self._keep.extend(keep)
+                self.fsmn_blocks[i] = blk
+                lw.fsmn = C.pointer(self.fsmn_blocks[i])
+                continue
             lw.w_gg = devw(g(f"{q}.global_gate.0.weight"))
             lw.b_gg = dev(g(f"{q}.global_gate.0.bias"))
             lw.w_in, lw.c1_in, lw.c2_in = fold_norm(g(f"{q}.proj_in.weight"), g(f"{q}.proj_in.bias"),
@@ -109,16 +118,19 @@ class PackedWeights:
         w.dec_w = dev(g("dec.weight")[:, 0, :])
         w.layers = C.cast(self.layers, C.POINTER(_lib.LayerWeights))
         self.struct = w
-        self.c_cfg = _lib.Config(cfg.dim, cfg.num_layers, cfg.enc_kernel, cfg.num_spks, precision)
+        self.c_cfg = _lib.Config(cfg.dim, cfg.num_layers, cfg.enc_kernel, cfg.num_spks, precision,
+                                 _lib.REC_FSMN if fsmn else _lib.REC_TCN, cfg.fsmn_inner)
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._keep)
 
 
-def pack_fsmn_block(state, device, prefix=""):
+def pack_fsmn_block(state, device, prefix="", precision=_lib.PREC_FP32):
     """Device weights of one Gated_FSMN_Block_Dilated (reference: mossformer2_block.py:434-463) for
-    msf2_gated_fsmn.  state: the block's state_dict (reference key names, optionally under prefix).
-    Returns (FsmnWeights struct, dim, inner, keep-alive list)."""
+    msf2_gated_fsmn / the FSMN form of msf2_forward.  state: the block's state_dict (reference key names,
+    optionally under prefix).  precision: MSF2_PREC_BF16 stores the projection matrices as bf16 (what the bf16
+    contraction kernels read).  Returns (FsmnWeights struct, dim, inner, keep-alive list)."""
+    bf16 = precision == _lib.PREC_BF16
     pre = (prefix + ".") if prefix else ""
     keep = []
 
@@ -130,10 +142,17 @@ def pack_fsmn_block(state, device, prefix=""):
         keep.append(t)
         return t.data_ptr()
 
+    def devw(t):
+        if not bf16:
+            return dev(t)
+        t = t.to(torch.float32).to(torch.bfloat16).contiguous().to(device)
+        keep.append(t)
+        return t.data_ptr()
+
     w = _lib.FsmnWeights()
     w1 = g("conv1.0.weight")[:, :, 0]
     inner, dim = w1.shape
-    w.w1, w.b1, w.prelu1 = dev(w1), dev(g("conv1.0.bias")), float(g("conv1.1.weight")[0])
+    w.w1, w.b1, w.prelu1 = devw(w1), dev(g("conv1.0.bias")), float(g("conv1.1.weight")[0])
     w.ln1_g, w.ln1_b = dev(g("norm1.weight")), dev(g("norm1.bias"))
     Ws, c1s, c2s, dws = [], [], [], []
     for br in ("to_u", "to_v"):
@@ -143,16 +162,16 @@ def pack_fsmn_block(state, device, prefix=""):
         Wf = (W * gain[None, :]).float()                  # LayerNorm(x) W^T + b = rstd (x W'^T - mean c2) + c1
         Ws.append(Wf)
         c1s.append((W @ beta + b).float())
-        c2s.append(Wf.double().sum(1).float())
+        c2s.append((Wf.to(torch.bfloat16) if bf16 else Wf).double().sum(1).float())   # over the weights as the kernel sees them
         dws.append(g(f"{q}.3.sequential.1.conv.weight")[:, 0, :])
-    w.w_uv, w.c1_uv, w.c2_uv = dev(torch.cat(Ws, 0)), dev(torch.cat(c1s, 0)), dev(torch.cat(c2s, 0))
+    w.w_uv, w.c1_uv, w.c2_uv = devw(torch.cat(Ws, 0)), dev(torch.cat(c1s, 0)), dev(torch.cat(c2s, 0))
     w.dw_uv = dev(torch.cat(dws, 0).t())
     f = "gated_fsmn.fsmn"
-    w.w_lin, w.b_lin, w.w_proj = dev(g(f"{f}.linear.weight")), dev(g(f"{f}.linear.bias")), dev(g(f"{f}.project.weight"))
+    w.w_lin, w.b_lin, w.w_proj = devw(g(f"{f}.linear.weight")), dev(g(f"{f}.linear.bias")), devw(g(f"{f}.project.weight"))
     w.w_c1 = dev(g(f"{f}.conv.conv1.weight")[:, 0, :, 0].t())                  # [39][C]
     w.in1_g, w.in1_b, w.pr1 = dev(g(f"{f}.conv.norm1.weight")), dev(g(f"{f}.conv.norm1.bias")), dev(g(f"{f}.conv.prelu1.weight"))
     w.w_c2 = dev(g(f"{f}.conv.conv2.weight")[:, :, :, 0].permute(2, 1, 0))       # [C][2][39] -> [39][2][C]
     w.in2_g, w.in2_b, w.pr2 = dev(g(f"{f}.conv.norm2.weight")), dev(g(f"{f}.conv.norm2.bias")), dev(g(f"{f}.conv.prelu2.weight"))
     w.ln2_g, w.ln2_b = dev(g("norm2.weight")), dev(g("norm2.bias"))
-    w.w2, w.b2 = dev(g("conv2.weight")[:, :, 0]), dev(g("conv2.bias"))
+    w.w2, w.b2 = devw(g("conv2.weight")[:, :, 0]), dev(g("conv2.bias"))
     return w, int(dim), int(inner), keep

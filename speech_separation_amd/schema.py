@@ -22,6 +22,39 @@ def _ffconvm(prefix, d_in, d_out, k, out):
     out[f"{prefix}.mdl.3.sequential.1.conv.weight"] = (d_out, 1, k)
 
 
+def _fsmn_block(p, d, inner, k, out):
+    """Gated_FSMN_Block_Dilated (reference: mossformer2_block.py:447-455, Gated_FSMN_dilated :370-382, FFConvM with
+    nn.LayerNorm :88-94, UniDeepFsmn_dilated fsmn.py:93-104, DilatedDenseNet fsmn.py:64-82 with lorder 20 -> 39 taps)."""
+    out[f"{p}.conv1.0.weight"] = (inner, d, 1)
+    out[f"{p}.conv1.0.bias"] = (inner,)
+    out[f"{p}.conv1.1.weight"] = (1,)
+    out[f"{p}.norm1.weight"] = (inner,)
+    out[f"{p}.norm1.bias"] = (inner,)
+    for br in ("to_u", "to_v"):
+        q = f"{p}.gated_fsmn.{br}.mdl"
+        out[f"{q}.0.weight"] = (inner,)
+        out[f"{q}.0.bias"] = (inner,)
+        out[f"{q}.1.weight"] = (inner, inner)
+        out[f"{q}.1.bias"] = (inner,)
+        out[f"{q}.3.sequential.1.conv.weight"] = (inner, 1, k)
+    f = f"{p}.gated_fsmn.fsmn"
+    out[f"{f}.linear.weight"] = (inner, inner)
+    out[f"{f}.linear.bias"] = (inner,)
+    out[f"{f}.project.weight"] = (inner, inner)
+    out[f"{f}.conv.conv1.weight"] = (inner, 1, 39, 1)
+    out[f"{f}.conv.norm1.weight"] = (inner,)
+    out[f"{f}.conv.norm1.bias"] = (inner,)
+    out[f"{f}.conv.prelu1.weight"] = (inner,)
+    out[f"{f}.conv.conv2.weight"] = (inner, 2, 39, 1)
+    out[f"{f}.conv.norm2.weight"] = (inner,)
+    out[f"{f}.conv.norm2.bias"] = (inner,)
+    out[f"{f}.conv.prelu2.weight"] = (inner,)
+    out[f"{p}.norm2.weight"] = (inner,)
+    out[f"{p}.norm2.bias"] = (inner,)
+    out[f"{p}.conv2.weight"] = (d, inner, 1)
+    out[f"{p}.conv2.bias"] = (d,)
+
+
 def state_dict_schema(cfg: MossFormer2Config) -> "OrderedDict[str, tuple]":
     """Ordered mapping key -> shape, in the order ``nn.Module.state_dict`` of
     the reference model yields them."""
@@ -41,7 +74,9 @@ def state_dict_schema(cfg: MossFormer2Config) -> "OrderedDict[str, tuple]":
         o[f"{p}.qk_offset_scale.gamma"] = (4, cfg.qk_dim)
         o[f"{p}.qk_offset_scale.beta"] = (4, cfg.qk_dim)
         _ffconvm(f"{p}.to_out", cfg.vdim, d, cfg.dw_kernel, o)
-    for i in range(L):
+    for i in range(L if cfg.recurrent == "fsmn" else 0):
+        _fsmn_block(f"{MDL}.fsmn.{i}", d, cfg.fsmn_inner, cfg.dw_kernel, o)
+    for i in range(0 if cfg.recurrent == "fsmn" else L):
         p = f"{MDL}.fsmn.{i}"
         o[f"{p}.norm.weight"] = (d,)
         o[f"{p}.norm.bias"] = (d,)

@@ -25,7 +25,9 @@ def _rng(key: str, base_seed: int) -> np.random.Generator:
 def _is_norm_gain(key: str) -> bool:
     return (key.endswith(".norm.weight") or key.endswith("intra_norm.weight")
             or key.endswith(".net.2.weight") or key.endswith(".g")
-            or key.endswith("pos_enc.scale"))
+            or key.endswith("pos_enc.scale")
+            # FSMN-family block: CLayerNorm / InstanceNorm gains and the LayerNorm gain of its FFConvM branches
+            or key.endswith(".norm1.weight") or key.endswith(".norm2.weight") or key.endswith(".mdl.0.weight"))
 
 
 def make_state_dict(cfg: MossFormer2Config, base_seed: int = 0) -> "OrderedDict[str, np.ndarray]":
@@ -45,6 +47,8 @@ def make_state_dict(cfg: MossFormer2Config, base_seed: int = 0) -> "OrderedDict[
             a = 0.1 * r.standard_normal(shape)
         elif key.endswith("prelu.weight"):
             a = np.full(shape, 0.25)
+        elif key.endswith(".conv1.1.weight") or key.endswith(".prelu1.weight") or key.endswith(".prelu2.weight"):
+            a = 0.25 + 0.05 * r.standard_normal(shape)      # PReLU slopes of the FSMN-family block
         elif _is_norm_gain(key):
             a = 1.0 + 0.1 * r.standard_normal(shape)
         elif len(shape) >= 2:

