@@ -642,7 +642,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     msf2_taps tp = {};
     if (taps) tp = *taps;
 
-    hipMemsetAsync(w.zeros, 0, 4096, c.st);  // zero operand rows for the token shift at frame 0
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, c.st, reinterpret_cast<float4*>(w.zeros), 256);  // zero operand rows for the token shift at frame 0
     // encoder + statistics for the mask net's GroupNorm(1, C, eps 1e-8)
     hipLaunchKernelGGL(encoder_kernel, dim3(w.nblk_enc, B), dim3(256), 0, c.st, mix, wt->enc_w, w.enc, w.part, T, S, C, ENC_TS);
     launch_stats_finalize(c, w.part, w.nblk_enc, (long)S * C, 1e-8f, w.bstat);
@@ -779,7 +779,7 @@ int msf2_linear(const float* x, int ldx, const float* W, const float* b, float* 
     }
     if (shift) {
         a.zeros = (float*)((char*)ws + align_up((size_t)B * S * sizeof(float)));
-        hipMemsetAsync((void*)a.zeros, 0, 256, c.st);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(64), 0, c.st, reinterpret_cast<float4*>(const_cast<float*>(a.zeros)), 16);
     }
     if (shift) launch_proj<A_SHIFT, EPI_RS_BIAS_ACT>(c, a);
     else launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);

@@ -7,6 +7,15 @@
 
 namespace msf2 {
 
+// ---- zero a small buffer (n16 16-byte units).  Used instead of hipMemsetAsync for the zero operand rows of the
+// token shift: the launch sequence must stay correct when it is captured into a HIP graph and replayed, and a
+// captured memset node was seen to fill with a stale pattern on later replays (ROCm 7.2).
+__global__ void zero_fill_kernel(float4* __restrict__ p, int n16) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+
 // Mapping used by the per-frame kernels: a 256-thread block covers
 // nf = 256 / (C/4) frames at a time, thread = (frame offset fo, channel quad cq).
 // Requires C in {64, 128, 256, 512, 1024}.

@@ -186,12 +186,21 @@ class MossFormerHIP(nn.Module):
                                               ws.data_ptr(), nbytes, None, torch.cuda.current_stream(dev).cuda_stream)
                     _lib.check(rc, "msf2_forward (graph capture)")
                 torch.cuda.current_stream(dev).wait_stream(side)
-                ent = (graph, xin, out, ws)
+                ent = (graph, xin, out, ws, side)
                 self._graphs[(B, T)] = ent
-            graph, xin, out, _ = ent
-            xin.copy_(x.detach().to(dtype=torch.float32), non_blocking=True)
-            graph.replay()
-            return out.clone()
+            graph, xin, out, _, side = ent
+            # The graph is always launched on the stream it was captured on, ordered against the caller's stream by
+            # events on both sides (launched on the null stream, replays were not ordered against the copies around
+            # them on ROCm 7.2).  Replays of one shape therefore run one after the other.
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                xin.copy_(x.detach().to(dtype=torch.float32), non_blocking=True)
+                graph.replay()
+                res = out.clone()
+            cur.wait_stream(side)
+            res.record_stream(cur)
+            return res
 
 
 class MossFormer2_SS(nn.Module):

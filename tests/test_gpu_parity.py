@@ -444,6 +444,54 @@ def test_long_form_matches_reference(models, golden_dir, name):
     assert abs(d) <= (0.05 if name == "full" else 0.1)
 
 
+@pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_BF16])
+def test_forward_ignores_workspace_contents(prec):
+    """The caller owns the workspace and hands it over uninitialised: results must not depend on what it holds
+    (zeros, NaN patterns, large finite values, or what an earlier forward of another input left there)."""
+    from speech_separation_amd.config import MossFormer2Config
+    lib = _lib.load()
+    for cfg, B, T in ((TINY, 2, 8003), (MossFormer2Config(num_layers=2), 1, 32000), (MossFormer2Config(num_layers=2), 3, 12000)):
+        m = MossFormerHIP(cfg, compute_device=DEV, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 0).items()})
+        pk = m.packed()
+        x = torch.from_numpy(synth_batch(B, T, seed0=0)).to(DEV)
+        other = torch.from_numpy(synth_batch(B, T, seed0=50)).to(DEV)
+        n = lib.msf2_workspace_bytes(pk.c_cfg, B, T)
+        outs = []
+        for fill in (0x00, 0xFF, 0x7F, None):
+            ws = torch.full((n,), fill or 0, dtype=torch.uint8, device=DEV)
+            out = torch.empty((2, B, T), device=DEV)
+            if fill is None:        # leftovers of a forward of another input
+                _lib.check(lib.msf2_forward(pk.c_cfg, pk.struct, other.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), n, None, None))
+            _lib.check(lib.msf2_forward(pk.c_cfg, pk.struct, x.data_ptr(), out.data_ptr(), B, T, ws.data_ptr(), n, None, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert torch.isfinite(outs[0]).all()
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+
+def test_graph_replay_matches_eager():
+    """use_graphs=True replays the captured launch sequence of a shape: bit-identical to the eager forward, for
+    calls issued back to back without a host synchronisation and for a second shape, fp32 and bf16."""
+    from speech_separation_amd.config import MossFormer2Config
+    cfg = MossFormer2Config(num_layers=3)
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 0).items()}
+    for prec in (_lib.PREC_FP32, BF):
+        m = MossFormerHIP(cfg, compute_device=DEV, precision=prec)
+        m.load_state_dict(sd)
+        xs = [torch.from_numpy(synth_batch(1, 32000, seed0=s)).to(DEV) for s in range(3)]
+        xs.append(torch.from_numpy(synth_batch(2, 12000, seed0=9)).to(DEV))
+        want = [torch.stack(m(x), 0) for x in xs]
+        m.use_graphs = True
+        got = [torch.stack(m(x), 0) for x in xs + xs]          # no synchronisation in between
+        torch.cuda.synchronize()
+        again = [torch.stack(m(x), 0) for x in xs]
+        for g, w in zip(got + again, want + want + want):
+            assert torch.equal(g, w)
+        assert len(m._graphs) == 2                                # one graph per input shape
+
+
 def test_forward_is_reentrant_across_threads(models):
     """A threaded server shares one model object (reference: app.py:256-259, Flask's threaded dev server): four
     host threads, each on its own HIP stream, separate different inputs at the same time (one of them with the
