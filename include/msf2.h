@@ -190,7 +190,7 @@ int msf2_timing_end(double* total_ms, int* launches);
 /* Test aid with no counterpart in the reference: overrides, for the CALLING THREAD only, which of the equivalent
  * kernel geometries the bf16 projections use (every choice performs the same arithmetic in the same order, so
  * results must be bit-identical; the parity tests check exactly that).  name: "ncol_loop", "big_maxn", "no_big",
- * "geom2" (integers as text) or "geom3", "geom4" (letters naming projections).  name == NULL restores the
+ * "geom2", "narrow" (integers as text) or "geom3", "geom4" (letters naming projections).  name == NULL restores the
  * defaults.  The library reads no environment variable. */
 int msf2_debug_kernel_choice(const char* name, const char* value);
 

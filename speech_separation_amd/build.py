@@ -12,10 +12,13 @@ OUT = os.path.join(HERE, "lib", "libmsf2.so")
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if os.environ.get("MSF2_CXXFLAGS"):
+        force = True                 # diagnostic builds never reuse the product library
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm", SRC, "-o", OUT]
+    extra = os.environ.get("MSF2_CXXFLAGS", "").split()
+    cmd = [hipcc, "-O3", *extra, "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-inline-asm", SRC, "-o", OUT]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

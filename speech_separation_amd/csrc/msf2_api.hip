@@ -61,6 +61,7 @@ struct Knobs {
     int big_maxn = 4096;        // "big_maxn": widest projection that may leave that form
     bool no_big = false;        // "no_big": 128 x 128 stream form only
     int geom2 = -1;             // "geom2": 0 / 1 forces the 128 x 256 geometry off / on
+    bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
 };
@@ -160,6 +161,14 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         return a.sq_part ? DmaGeom<P, 0>::TN * 32 : 0;
     }
     if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return 0; }     // only the DMA kernel reads the bf16 gate
+    if constexpr (AMODE == A_PLAIN && !P::PAIRED) {
+        // fp32, fewer 128-wide tiles than CUs (one utterance per call): 64-wide tiles, twice the workgroups
+        if (c.prec != MSF2_PREC_BF16 && (long)grid.x * grid.y * grid.z < 256 && a.N >= 128 && c.k.narrow) {
+            grid.x = cdiv(a.N, 64);
+            hipLaunchKernelGGL((gemm_kernel<P, 64>), grid, dim3(256), 0, c.st, a);
+            return a.sq_part ? 64 / P::WC : 0;
+        }
+    }
     launch_gemm<P>(c, grid, a);
     // the fp32 kernel finishes tiles with the row-major epilogue (64-column wave slabs); the register-staged bf16 one does not
     return (a.sq_part && c.prec != MSF2_PREC_BF16) ? BN / P::WC : 0;
@@ -518,7 +527,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.pe = ar.take<float>((long)S * C);
     w.fv = ar.take<float>(M * 16);
     w.zeros = ar.take<float>(1024);      // >= K bytes: the DMA kernel's copy address of a zero row advances with k
-    w.sqx = ar.take<float>((long)B * S * cdiv(C, 64));   // partial row sums of squares of x, slabs of >= 64 columns
+    w.sqx = ar.take<float>((long)B * S * cdiv(C, 32));   // partial row sums of squares of x, slabs of >= 32 columns
     w.x16 = w.o16 = w.hu_pre16 = w.hu16 = nullptr;
     if (cfg.precision == MSF2_PREC_BF16) {
         w.hu_pre16 = ar.take<unsigned short>(M * NH);
@@ -612,6 +621,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "big_maxn")) k.big_maxn = atoi(value);
     else if (!strcmp(name, "no_big")) k.no_big = atoi(value) != 0;
     else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
+    else if (!strcmp(name, "narrow")) k.narrow = atoi(value) != 0;
     else if (!strcmp(name, "geom3")) { strncpy(k.g3, value, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }
     else if (!strcmp(name, "geom4")) { strncpy(k.g4, value, sizeof(k.g4) - 1); k.g4[sizeof(k.g4) - 1] = 0; }
     else return MSF2_ERR_ARG;

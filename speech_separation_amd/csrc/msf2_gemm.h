@@ -34,8 +34,8 @@ namespace msf2 {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 enum { ORI_KC = 0, ORI_RC = 1 };   // operand tile is k-contiguous / row-contiguous in global memory
-template <int ORI> struct LdsTile {
-    static constexpr int SIZE = (ORI == ORI_KC) ? BM * BK : BK * (BM + 4);   // floats
+template <int ORI, int ROWS = BM> struct LdsTile {      // ROWS: operand rows in the tile (128, or 64 for the narrow B tile)
+    static constexpr int SIZE = (ORI == ORI_KC) ? ROWS * BK : BK * (BM + 4);   // floats
 };
 constexpr int RC_PITCH = BM + 4;
 
@@ -105,12 +105,12 @@ __device__ __forceinline__ void stg4_bf16_off(unsigned short* base, unsigned byt
     *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + byte_off) = h;
 }
 
-// ---- k-contiguous operand: 16 KiB tile = 16 wave-level DMA instructions, 4 per wave
-template <class P, int SEG, bool IS_A>
+// ---- k-contiguous operand: 128-row tile = 16 KiB = 16 wave-level DMA instructions, 4 per wave (ROWS / 32 per wave)
+template <class P, int SEG, bool IS_A, int ROWS = BM>
 __device__ __forceinline__ void dma_tile(const P& prob, float* tile, int kt, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;
+    for (int i = 0; i < ROWS / 32; ++i) {
+        const int inst = wave * (ROWS / 32) + i;
         const int row = inst * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ kc_swz(row);          // logical chunk stored at position lane & 7
         const float* src;
@@ -144,10 +144,11 @@ __device__ unsigned long long g_stamp2[2048 * 4 * 2];
 #define MSF2_STAMP(x)
 #endif
 
-template <class P, int SEG, int TM, int TN>
+template <class P, int SEG, int TM, int TN, int BNT = BN>
 __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* smB,
                                             f32x16 (&acc)[TM][TN], int tid, int lane, int wave, int wr, int wc) {
-    constexpr int SZA = LdsTile<P::A_ORI>::SIZE, SZB = LdsTile<P::B_ORI>::SIZE;
+    constexpr int SZA = LdsTile<P::A_ORI>::SIZE, SZB = LdsTile<P::B_ORI, BNT>::SIZE;
+    static_assert(BNT == BN || P::B_ORI == ORI_KC, "the narrow B tile is for k-contiguous operands");
     constexpr bool A_DMA = P::A_ORI == ORI_KC, B_DMA = P::B_ORI == ORI_KC;
     const int nk = prob.nk(SEG);
     float4 ra[A_DMA ? 1 : 4], rb[B_DMA ? 1 : 4];
@@ -157,7 +158,7 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
 #pragma unroll
             for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); ra[i] = prob.fetchA(SEG, kt, r, k); }
         }
-        if constexpr (B_DMA) dma_tile<P, SEG, false>(prob, smB + buf * SZB, kt, wave, lane);
+        if constexpr (B_DMA) dma_tile<P, SEG, false, BNT>(prob, smB + buf * SZB, kt, wave, lane);
         else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { int r, k; rc_coords(tid, i, r, k); rb[i] = prob.fetchB(SEG, kt, r, k); }
@@ -242,19 +243,24 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
     __syncthreads();
 }
 
-template <class P>
+// BNT: output columns per tile.  128 normally; 64 (projections only) when the 128-wide tiling would give fewer
+// workgroups than the chip has CUs -- one utterance per call, the callers' own shape: twice the workgroups, each with
+// half the accumulators.  Per output element the arithmetic is the same in both forms (same k order).
+template <class P, int BNT = BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args args) {
     __shared__ __attribute__((aligned(1024))) float smA[2 * LdsTile<P::A_ORI>::SIZE];
-    __shared__ __attribute__((aligned(1024))) float smB[2 * LdsTile<P::B_ORI>::SIZE];
+    __shared__ __attribute__((aligned(1024))) float smB[2 * LdsTile<P::B_ORI, BNT>::SIZE];
 #ifdef MSF2_DIAG_STAMP
     unsigned long long tk0, tk1, tk2;
     MSF2_STAMP(tk0)
 #endif
     P prob;
-    prob.init(args);
+    if constexpr (BNT == BN) prob.init(args);
+    else prob.init_tile(args, BM, BNT);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / P::WC, wc = wave % P::WC;
-    constexpr int TM = BM / (32 * P::WR), TN = BN / (32 * P::WC);
+    constexpr int TM = BM / (32 * P::WR), TN = BNT / (32 * P::WC);
+    static_assert(TN >= 1 && TN * 32 * P::WC == BNT, "tile columns must split evenly over the waves");
     f32x16 acc[P::NACC][TM][TN];     // NACC accumulator sets; the K segments of a problem with NACC = 1 share one
 #pragma unroll
     for (int s = 0; s < P::NACC; ++s)
@@ -264,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][tm][tn][r] = 0.f;
-    run_segment<P, 0, TM, TN>(prob, smA, smB, acc[0], tid, lane, wave, wr, wc);
-    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN>(prob, smA, smB, acc[P::NACC - 1], tid, lane, wave, wr, wc);
+    run_segment<P, 0, TM, TN, BNT>(prob, smA, smB, acc[0], tid, lane, wave, wr, wc);
+    if constexpr (P::NSEG == 2) run_segment<P, 1, TM, TN, BNT>(prob, smA, smB, acc[P::NACC - 1], tid, lane, wave, wr, wc);
 #ifdef MSF2_DIAG_NOEPI
     {   // timing-only build: keep the accumulators alive with one store per thread
         float sum = 0.f;

@@ -444,6 +444,41 @@ def test_long_form_matches_reference(models, golden_dir, name):
     assert abs(d) <= (0.05 if name == "full" else 0.1)
 
 
+def test_narrow_tiles_agree_with_wide_tiles(models, golden_dir):
+    """One utterance per call (the callers' own shape): the fp32 projections then run on 64-column tiles so that
+    the launch fills the chip.  Each output element is accumulated in the same order as on 128-column tiles; only
+    the ScaleNorm partial sums are grouped differently (32- instead of 64-column slabs), so the two forms agree to
+    fp32 rounding, and both match the reference fixture."""
+    lib = _lib.load()
+    z = np.load(os.path.join(golden_dir, "fwd_full_B1_T32000.npz"))
+    x = torch.from_numpy(z["input"]).to(DEV)
+    m = models("full")
+    outs = {}
+    for narrow in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(b"narrow", narrow))
+        try:
+            outs[narrow] = torch.stack(m(x), 0).cpu().numpy()
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    peak = np.abs(z["out"]).max()
+    assert np.abs(outs[b"1"] - outs[b"0"]).max() <= 1e-5 * peak
+    for o in outs.values():
+        assert np.abs(o - z["out"]).max() <= 1e-3 * peak
+    # a single projection is bit-identical in the two forms
+    g = torch.Generator().manual_seed(41)
+    xx = torch.randn(1, 3999, 512, generator=g).to(DEV)
+    W = (torch.randn(512, 512, generator=g) / 512 ** 0.5).to(DEV)
+    bias = (torch.randn(512, generator=g) * 0.1).to(DEV)
+    ys = []
+    for narrow in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(b"narrow", narrow))
+        try:
+            ys.append(ops.linear(xx, W, bias, act=1))
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    assert torch.equal(ys[0], ys[1])
+
+
 @pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_BF16])
 def test_forward_ignores_workspace_contents(prec):
     """The caller owns the workspace and hands it over uninitialised: results must not depend on what it holds
