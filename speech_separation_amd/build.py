@@ -1,4 +1,5 @@
 """Build libmsf2.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,11 +11,31 @@ DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("msf2_common.h", "msf2_g
 OUT = os.path.join(HERE, "lib", "libmsf2.so")
 
 
+STAMP = OUT + ".sources.sha256"
+
+
+def sources_digest() -> str:
+    """SHA-256 over the sources the library is built from (and the flags): the library is rebuilt whenever this
+    differs from the digest recorded beside it, whatever the files' time stamps say (a fresh clone, a checkout)."""
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    h.update(os.environ.get("MSF2_CXXFLAGS", "").encode())
+    return h.hexdigest()
+
+
+def up_to_date() -> bool:
+    try:
+        with open(STAMP) as f:
+            return os.path.exists(OUT) and f.read().strip() == sources_digest()
+    except OSError:
+        return False
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if os.environ.get("MSF2_CXXFLAGS"):
-        force = True                 # diagnostic builds never reuse the product library
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+    if not force and up_to_date():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("MSF2_CXXFLAGS", "").split()
@@ -22,6 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(sources_digest() + "\n")
     return OUT
 
 

@@ -630,6 +630,50 @@ def test_sweep_statistic_on_device(models):
     assert abs(stats[0] - sum(host)) <= 3e-3
 
 
+def test_sweep_of_mixed_lengths_on_the_full_model(models):
+    """A small edition of the sharded sweep (exact-length buckets, longest first, batches capped by samples) on the
+    24-layer model: every utterance comes back at its own length and equals the forward of that utterance alone;
+    the SI-SDR statistic reduced on the device equals the host formula."""
+    from speech_separation_amd.parallel import separate_sharded
+    from speech_separation_amd.synth import permute_si_sdr, synth_mixture
+    m = models("full")
+    lens = [24000, 32000, 24000, 40000, 32000, 24000, 28000]
+    data = [synth_mixture(n, 200 + i) for i, n in enumerate(lens)]
+    utts, refs = [d[0] for d in data], [(d[1], d[2]) for d in data]
+    calls = []
+
+    def fn(x):
+        calls.append(tuple(x.shape))
+        return m(x)
+    outs, stats = separate_sharded(fn, utts, device=DEV, references=refs, max_batch=2)
+    assert sorted(calls) == sorted([(1, 40000), (2, 32000), (1, 28000), (2, 24000), (1, 24000)])
+    for i in (0, 3, 4):
+        alone = torch.stack(m(torch.from_numpy(utts[i][None]).to(DEV)), 0)[:, 0].cpu().numpy()
+        assert outs[i].shape == (2, lens[i])
+        assert np.abs(outs[i] - alone).max() <= 1e-5 * np.abs(alone).max()
+    host = [permute_si_sdr(o[0], o[1], r[0], r[1]) for o, r in zip(outs, refs)]
+    assert stats[2] == len(lens) and abs(stats[0] - sum(host)) <= 5e-3
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "tinyfsmn"])
+def test_bf16_mode_on_reference_fixtures(golden_dir, name):
+    """bf16 MFMA mode on the small reference fixtures: the separated waveforms stay within 30 dB (SI-SDR of the
+    estimate against the reference model's own fp32 output) for every utterance and speaker."""
+    from speech_separation_amd.synth import si_sdr
+    m = MossFormerHIP(CFG[name], compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(CFG[name], 0).items()})
+    worst = 1e9
+    for f in sorted(glob.glob(os.path.join(golden_dir, f"fwd_{name}_B*.npz"))):
+        z = np.load(f)
+        got = torch.stack(m(torch.from_numpy(z["input"]).to(DEV)), 0).cpu().numpy()
+        assert np.isfinite(got).all()
+        for s in range(got.shape[0]):
+            for b in range(got.shape[1]):
+                worst = min(worst, si_sdr(got[s, b], z["out"][s, b]))
+    print(f"bf16 mode, {name} fixtures: worst fidelity {worst:.1f} dB")
+    assert worst >= 30.0
+
+
 def test_gated_fsmn_block(golden_dir):
     """FSMN-family block: against the reference module's outputs (fixture, dim 64 / inner 64) and, at the
     reference's real size (dim 512, inner 256), against the fp64 oracle."""

@@ -43,6 +43,14 @@ def test_library_exports_every_declared_symbol():
     assert lib.msf2_strerror(-2).decode() == "workspace too small"
 
 
+def test_library_was_built_from_these_sources():
+    """The shared library that ships with the tree (it is not tracked by git) carries a digest of the sources it
+    was compiled from; a library left over from other sources fails here instead of being tested by mistake."""
+    from speech_separation_amd import build
+    assert os.path.exists(build.OUT)
+    assert build.up_to_date(), "libmsf2.so is stale: run `python -m speech_separation_amd.build`"
+
+
 def test_workspace_query_runs_without_gpu():
     lib = _lib.load()
     cfg = _lib.Config(512, 24, 16, 2, _lib.PREC_FP32)

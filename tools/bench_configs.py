@@ -1,7 +1,7 @@
 """Secondary workloads of the benchmark list, one JSON line each.
 
     python tools/bench_configs.py --config c4 [--precision fp32|bf16]
-        one 60 s 8 kHz mixture (long-sequence grouped attention, 59 999 frames), batch 1
+        one 60 s 8 kHz mixture as the decode harness pads it (492000 samples, 61 499 frames, 241 groups), batch 1
     python tools/bench_configs.py --config c5 [--precision ...] [--utterances 3000]
         Libri2Mix-test-sized sweep: synthetic utterances of 3-15 s (lengths on a 0.5 s grid so that
         equal-length utterances can share a batch), utterance-sharded over the ranks of
@@ -56,7 +56,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     if a.config == "c4":
-        T = 60 * 8000
+        # what the decode harness feeds the model for a 60 s file: 480000 samples padded to 492000
+        # (reference: utils/decode.py:43-51); the rate is quoted on the 60 s of audio it came from
+        from speech_separation_amd.decode import padded_length
+        T = padded_length(60 * 8000, 8000, 6000)
+        assert T == 492000
         x = torch.from_numpy(synth_batch(1, T, seed0=7)).to(dev)
         model(x)
         sync()
@@ -65,7 +69,7 @@ def main():
             out = model(x)
         sync()
         dt = (time.perf_counter() - t0) / a.reps
-        res = {"config": "c4: one 60 s 8 kHz mixture, batch 1", "precision": a.precision, "n_gpus": world,
+        res = {"config": "c4: one 60 s 8 kHz mixture, batch 1 (492000 samples after the decode padding rule)", "precision": a.precision, "n_gpus": world,
                "audio_s_per_s": world * 60.0 / dt, "ms_per_utterance": 1e3 * dt,
                "finite": bool(torch.isfinite(torch.stack(out)).all().item())}
     else:
