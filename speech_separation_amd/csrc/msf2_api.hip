@@ -10,6 +10,7 @@
 #include "msf2_common.h"
 #include "msf2_gemm.h"
 #include "msf2_gemm_bf16.h"
+#include "msf2_attn_fused.h"
 #include "msf2_ops.h"
 
 namespace msf2 {
@@ -61,6 +62,8 @@ struct Knobs {
     int big_maxn = 4096;        // "big_maxn": widest projection that may leave that form
     bool no_big = false;        // "no_big": 128 x 128 stream form only
     int geom2 = -1;             // "geom2": 0 / 1 forces the 128 x 256 geometry off / on
+    int attn_fused_min = 256;   // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken
+    bool attn_fused = true;     // "attn_fused": bf16 mode, attention scores kept on chip (one kernel) instead of the two-kernel form
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -237,7 +240,7 @@ static AttnWs attn_ws(Arena& ar, int B, int S, int E) {
     w.P = ar.take<float>((long)B * w.G * MSF2_GROUP * MSF2_GROUP);
     w.part = ar.take<float>((long)B * w.nsplit * MSF2_QK_DIM * 2 * E);
     w.kv = ar.take<float>((long)B * MSF2_QK_DIM * 2 * E);
-    w.sqp = ar.take<float>((long)B * S * (E / (BN / 2)));
+    w.sqp = ar.take<float>((long)B * S * (E / 32));     // partial sums of o^2: 64-column slabs, 32-column ones from the fused kernel
     return w;
 }
 // o_rnorm: optional [M] ScaleNorm inverse norms of the output rows (from partial sums the output kernel writes)
@@ -261,6 +264,18 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
         else launch_gemm<LinKV>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
         const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
+    }
+    if (hu16 && c.k.attn_fused && (E % 64) == 0 && 2L * c.B * w.G >= c.k.attn_fused_min) {
+        // bf16 mode: scores, both products and the gating in one kernel; the scores never leave the chip
+        // (one workgroup per half group and CU: below about one workgroup per CU the two-kernel form, whose
+        // grid is E / 64 times larger, fills the chip better -- measured equal at 256 workgroups, 6 % slower at 128)
+        AttnFusedArgs a = {reinterpret_cast<const unsigned short*>(quad_q), reinterpret_cast<const unsigned short*>(quad_k),
+                           reinterpret_cast<const unsigned short*>(lin_q), hu16, ldhu, w.kv, o16, o_rnorm ? w.sqp : nullptr, c.S, w.G, E};
+        if (!o16) { g_bad_operand = true; return; }
+        hipLaunchKernelGGL(attn_fused_bf16_kernel, dim3(2, c.B * w.G), dim3(512), 0, c.st, a);
+        if (o_rnorm)
+            hipLaunchKernelGGL(rowsq_finalize_kernel, dim3(cdiv(M, 256)), dim3(256), 0, c.st, w.sqp, E / 32, o_rnorm, M, c.S, E, 0);
+        return;
     }
     {
         // bf16 mode: scores and lin_q exist as bf16 only (the values the contraction would round them to anyway)
@@ -622,6 +637,8 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "no_big")) k.no_big = atoi(value) != 0;
     else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
     else if (!strcmp(name, "narrow")) k.narrow = atoi(value) != 0;
+    else if (!strcmp(name, "attn_fused")) k.attn_fused = atoi(value) != 0;
+    else if (!strcmp(name, "attn_fused_min")) k.attn_fused_min = atoi(value);
     else if (!strcmp(name, "geom3")) { strncpy(k.g3, value, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }
     else if (!strcmp(name, "geom4")) { strncpy(k.g4, value, sizeof(k.g4) - 1); k.g4[sizeof(k.g4) - 1] = 0; }
     else return MSF2_ERR_ARG;
