@@ -1,7 +1,24 @@
 #!/bin/bash
-# Diagnostic helper: regenerates the bench lines and rocprofv3 kernel summaries kept under profiles/ on one GPU box
-# (bf16 64 x 4 s and fp32 16 x 4 s: the plain bench line, then the same command under rocprofv3 --kernel-trace --stats;
-# the profiled fp32 run leaves out the secondary bf16 measurement so that its kernel table is fp32 only).
+# Diagnostic helper: regenerates, on ONE GPU box, everything kept under profiles/ for this round (prefix given as $1,
+# default r2): the bench lines, the rocprofv3 kernel summaries of the same commands, the FETCH_SIZE / WRITE_SIZE passes
+# of the dominant kernel (separate --pmc runs), the long-form / sweep / batch-1 latency lines and the FSMN-form bench.
+P=${1:-r2}
 cd /root/repo
-timeout 1900 /usr/local/graft/bin/gpurun --timeout 1100 -- "timeout -k 10 200 python bench.py --precision bf16 --batch 64 > gpurun_out/bf16.json 2> gpurun_out/bf16.err && timeout -k 10 200 python bench.py > gpurun_out/fp32.json 2> gpurun_out/fp32.err && cd /tmp && export TMPDIR=/tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_bf16 -o a -- python3 /root/repo/bench.py --precision bf16 --batch 64 > /root/repo/gpurun_out/bf16_rocprof.json 2> /root/repo/gpurun_out/bf16_rocprof.err && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_fp32 -o a -- python3 /root/repo/bench.py --no-secondary > /root/repo/gpurun_out/fp32_rocprof.json 2> /root/repo/gpurun_out/fp32_rocprof.err" 2>&1 | grep -v "every call\|^\[gpurun\] sending"
-for f in bf16 fp32 bf16_rocprof fp32_rocprof; do tail -1 gpurun_out/$f.json | cut -c1-160; done
+O=/root/repo/gpurun_out/$P
+RP="rocprofv3 --kernel-trace --stats --output-format csv"
+cmd="mkdir -p $O && cd /tmp && export TMPDIR=/tmp"
+cmd="$cmd && timeout -k 10 300 python3 /root/repo/bench.py > $O/fp32_b16_bench.json 2> $O/fp32.err"
+cmd="$cmd && timeout -k 10 300 python3 /root/repo/bench.py --precision bf16 --batch 64 > $O/bf16_b64_bench.json 2> $O/bf16.err"
+cmd="$cmd && timeout -k 10 300 $RP -d $O/prof_fp32 -o a -- python3 /root/repo/bench.py --no-secondary > $O/fp32_b16_bench_under_rocprof.json 2> $O/fp32_rocprof.err"
+cmd="$cmd && timeout -k 10 300 $RP -d $O/prof_bf16 -o a -- python3 /root/repo/bench.py --precision bf16 --batch 64 --no-secondary > $O/bf16_b64_bench_under_rocprof.json 2> $O/bf16_rocprof.err"
+cmd="$cmd && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fp32_fetch -o a -- python3 /root/repo/tools/probe_op.py tcn_pointwise --reps 5 > $O/pmc1.out 2>&1"
+cmd="$cmd && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_fp32_write -o a -- python3 /root/repo/tools/probe_op.py tcn_pointwise --reps 5 > $O/pmc2.out 2>&1"
+cmd="$cmd && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bf16_fetch -o a -- python3 /root/repo/tools/time_tcn16.py > $O/pmc3.out 2>&1"
+cmd="$cmd && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bf16_write -o a -- python3 /root/repo/tools/time_tcn16.py > $O/pmc4.out 2>&1"
+cmd="$cmd && cd /root/repo"
+cmd="$cmd && timeout -k 10 200 python3 tools/bench_configs.py --config c4 > $O/c4_fp32.json 2>> $O/cfg.err && timeout -k 10 200 python3 tools/bench_configs.py --config c4 --precision bf16 > $O/c4_bf16.json 2>> $O/cfg.err"
+cmd="$cmd && timeout -k 10 400 python3 tools/bench_configs.py --config c5 > $O/c5_fp32.json 2>> $O/cfg.err && timeout -k 10 300 python3 tools/bench_configs.py --config c5 --precision bf16 > $O/c5_bf16.json 2>> $O/cfg.err"
+cmd="$cmd && timeout -k 10 200 python3 tools/latency_b1.py > $O/latency_b1.jsonl 2>> $O/cfg.err"
+cmd="$cmd && timeout -k 10 300 python3 bench.py --recurrent fsmn --no-cpu-baseline > $O/fsmn_fp32_b16_bench.json 2>> $O/cfg.err && timeout -k 10 300 python3 bench.py --recurrent fsmn --precision bf16 --batch 64 --no-cpu-baseline > $O/fsmn_bf16_b64_bench.json 2>> $O/cfg.err"
+timeout 2400 /usr/local/graft/bin/gpurun --timeout 1200 -- "$cmd" 2>&1 | grep -v "every call\|^\[gpurun\] sending"
+ls $O
