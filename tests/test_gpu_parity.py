@@ -253,6 +253,30 @@ def test_full_model_matches_reference(models, golden_dir):
     assert err64 <= 1e-3 * peak
 
 
+@pytest.mark.parametrize("B,T", [(1, 16), (2, 24), (1, 700), (3, 1031), (1, 2055)])
+def test_very_short_inputs_match_oracle(B, T):
+    """Edge cases of the frame grid: a single frame (T = 16), two frames, fewer frames than the largest TCN dilation
+    (every dilated tap of the late blocks falls outside the utterance and is zero padding, reference:
+    mossformer2_block.py:513-517), fewer frames than one attention group, a length that is no multiple of the hop.
+    HIP forward (fp32) against the fp64 oracle on the small configuration; bf16 mode must stay finite and close."""
+    from speech_separation_amd.synth import si_sdr
+    sd = make_state_dict(SMALL, 0)
+    x = torch.from_numpy(synth_batch(B, T, seed0=11))
+    with torch.no_grad():
+        ref = torch.stack(cpu_ref.forward(cpu_ref.to_torch(sd, torch.float64), x.double(), SMALL), 0)
+    m = MossFormerHIP(SMALL, compute_device=DEV)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    got = torch.stack(m(x.to(DEV)), 0).cpu()
+    assert got.shape == (2, B, T)
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9
+    m16 = MossFormerHIP(SMALL, compute_device=DEV, precision=BF)
+    m16.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    got16 = torch.stack(m16(x.to(DEV)), 0).cpu()
+    assert torch.isfinite(got16).all()
+    if T >= 700:
+        assert min(si_sdr(got16[s, b].numpy(), ref[s, b].numpy()) for s in range(2) for b in range(B)) >= 30.0
+
+
 def test_cpu_input_round_trip(models, golden_dir):
     """A CPU tensor in gives CPU tensors out (the Flask entry point feeds CPU tensors)."""
     z = np.load(os.path.join(golden_dir, "fwd_tiny_B1_T8000.npz"))
