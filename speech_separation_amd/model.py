@@ -125,6 +125,14 @@ class MossFormerHIP(nn.Module):
         B, T = x.shape
         if T < self.cfg.enc_kernel:
             raise ValueError(f"input shorter than the encoder kernel ({T} < {self.cfg.enc_kernel})")
+        # One library call addresses its widest activation with 32-bit byte offsets (about 3.9 M samples per call for the
+        # 512-channel model).  Utterances are independent, so a larger batch is separated in equal-sized pieces.
+        if taps is None and B > 1 and lib.msf2_workspace_bytes(pk.c_cfg, B, T) == 0 and lib.msf2_workspace_bytes(pk.c_cfg, 1, T) != 0:
+            step = B
+            while step > 1 and lib.msf2_workspace_bytes(pk.c_cfg, step, T) == 0:
+                step = (step + 1) // 2
+            parts = [self.forward(x[i:i + step]) for i in range(0, B, step)]
+            return [torch.cat([p[s] for p in parts], 0) for s in range(self.num_spks)]
         if self.use_graphs and taps is None:
             out = self._forward_graph(pk, x, B, T)
             outs = [out[s] for s in range(self.num_spks)]

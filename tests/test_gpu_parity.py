@@ -564,6 +564,22 @@ def test_forward_ignores_workspace_contents(prec):
             assert torch.equal(o, outs[0])
 
 
+def test_batches_beyond_one_call_are_split(models):
+    """A batch whose widest activation would pass 4 GiB (the kernels use 32-bit byte offsets) is separated in pieces:
+    same results as the utterances alone, no error for the caller."""
+    lib = _lib.load()
+    m = models("full")
+    B, T = 130, 32000                       # 4.16 M samples: one call takes at most about 3.9 M
+    assert lib.msf2_workspace_bytes(m.packed().c_cfg, B, T) == 0
+    x = torch.from_numpy(synth_batch(2, T, seed0=0)).to(DEV).repeat(B // 2, 1)
+    out = torch.stack(m(x), 0)
+    assert out.shape == (2, B, T) and torch.isfinite(out).all()
+    two = torch.stack(m(x[:2]), 0)
+    peak = float(two.abs().max())
+    assert float((out[:, :2] - two).abs().max()) <= 1e-5 * peak
+    assert float((out[:, 128:130] - two).abs().max()) <= 1e-5 * peak
+
+
 def test_graph_replay_matches_eager():
     """use_graphs=True replays the captured launch sequence of a shape: bit-identical to the eager forward, for
     calls issued back to back without a host synchronisation and for a second shape, fp32 and bf16."""
