@@ -56,3 +56,24 @@ def test_under_an_external_launcher_env_is_respected():
     r = _run(env, gpus=1)
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout.strip())["n_gpus"] == 1
+
+
+def test_under_torch_distributed_run():
+    """The way a multi-GPU run is launched from outside: `python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher).  bench.py must then be a rank, join the
+    launcher's rendezvous and print its single line on rank 0."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "2", "--seconds", "0.5", "--stub-cpu"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and len(rec["ms_per_step_per_rank"]) == 2
