@@ -111,6 +111,16 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         // 4 tiles re-reads A from the fabric 4 times (FETCH_SIZE 2.4 GB instead of 0.9 GB per launch).
         int loop = c.k.ncol_loop;
         ProjArgs al = a;
+        if constexpr (!P::PAIRED && AMODE == A_PLAIN) {
+            // fewer 128-row tiles than CUs (one utterance per call): 64-row tiles, twice the workgroups
+            if (c.k.narrow && (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B < 256 && (a.N % 128) == 0) {
+                typedef DmaGeom<P, 7> G7;
+                dim3 g(cdiv(a.N, G7::BNX), cdiv(c.S, G7::BMX), c.B);
+                al.ncol_loop = 1;
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 7>), g, dim3(G7::THREADS), 0, c.st, al);
+                return a.sq_part ? G7::TN * 32 : 0;
+            }
+        }
         if constexpr (!P::PAIRED && P::NSEG == 1) {
             // 256-row tiles, one 8-wave workgroup per CU, when that still gives every CU several tiles
             typedef DmaGeom<P, 1> G;

@@ -576,6 +576,7 @@ struct ProjNT {
                 if (EPI == EPI_NORM && a.pe) rv[i] = ldg4_off(a.pe, (mrow[i] - m_base) * (4u * a.N) + nc4);
                 if constexpr (has_g && RESLDS)
                     gp[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.gmul16) + ((mrow[i] * ldo4 + nc4) >> 1));
+                else if (has_g && a.gmul16) gv[i] = ldg4_bf16_off(a.gmul16, (mrow[i] * ldo4 + nc4) >> 1);   // (uniform branch)
                 else if (has_g) gv[i] = ldg4_off(a.gmul, mrow[i] * ldo4 + nc4);
                 if (ROWSTAT && has_rs) {
                     if (EPI == EPI_RS_BIAS_ACT) r0[i] = ldg_off(a.rowstat, mrow[i] * 4u);

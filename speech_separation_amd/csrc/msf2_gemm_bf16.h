@@ -249,11 +249,21 @@ template <class P> struct DmaGeom<P, 4> {
     static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 2, MINB = 4;
 };
 
+//   BIG = 7: 64 x 128 tile, 4 waves as 2 x 2 (32 x 64 per wave), 4-slot ring of 12 KB stages, two workgroups per CU.  For
+//            grids the 128-row tiling cannot spread over the chip (one utterance per call: 32 row tiles x 4 column
+//            tiles on 256 CUs): twice the workgroups.  One- and two-product problems; the two-product form reads its
+//            bf16 residual in the epilogue (no residual tiles in the ring) and keeps both accumulator sets (64 registers).
+template <class P> struct DmaGeom<P, 7> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 1, TN = 2;
+    static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 4, MINB = 2;
+};
+
 template <class P, int BIG>
 __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
     constexpr bool SMALL = (BIG == 0);                  // the 128 x 128 stream form: several column tiles, both products, residual tiles
-    static_assert(SMALL || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
+    static_assert(SMALL || BIG == 7 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
+    static_assert(!P::PAIRED || SMALL, "paired columns: 128 x 128 geometry only");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
     constexpr int TILE_A = G::BMX * 64, TILE_B = G::BNX * 64, STAGE = TILE_A + TILE_B;   // bytes
     constexpr int PA = G::BMX / 16 / NWAVES, PB = G::BNX / 16 / NWAVES;                  // copies per wave and k tile: 16 rows x 64 B each

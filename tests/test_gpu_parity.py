@@ -536,6 +536,21 @@ def test_narrow_tiles_agree_with_wide_tiles(models, golden_dir):
         finally:
             _lib.check(lib.msf2_debug_kernel_choice(None, None))
     assert torch.equal(ys[0], ys[1])
+    # bf16 mode: 64-row tiles of the global->LDS kernel for the same reason; same arithmetic per output element
+    from speech_separation_amd.synth import si_sdr
+    m16 = MossFormerHIP(FULL_8K, compute_device=DEV, precision=BF)
+    m16.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(FULL_8K, 0).items()})
+    o16 = []
+    for narrow in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(b"narrow", narrow))
+        try:
+            o16.append(torch.stack(m16(x), 0).cpu().numpy())
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    agree = min(si_sdr(o16[0][s_, 0], o16[1][s_, 0]) for s_ in range(2))
+    fid = min(si_sdr(o16[0][s_, 0], z["out"][s_, 0]) for s_ in range(2))
+    print(f"bf16 narrow vs wide tiles: identical {np.array_equal(o16[0], o16[1])}, agreement {agree:.1f} dB, fidelity to the reference {fid:.1f} dB")
+    assert agree >= 40.0 and fid >= 38.0
 
 
 @pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_BF16])
