@@ -1,5 +1,5 @@
 """Diagnostic: bf16 batch-64 forward time with a kernel-choice knob on and off (same process, same box).
-    python tools/ab_knob.py attn_fused [batch]"""
+    python tools/ab_knob.py attn_fused [batch [fp32]]        (AB_FIXED=name=value,... sets further knobs for both legs)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,10 @@ lib = _lib.load()
 m = MossFormerHIP(cfg, compute_device="cuda:0", precision=prec)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 0).items()})
 x = torch.from_numpy(synth_batch(B, 32000, seed0=0)).to("cuda:0")
+fixed = [kv.split("=") for kv in os.environ.get("AB_FIXED", "").split(",") if kv]     # e.g. AB_FIXED=no_big=1
 for val in (b"1", b"0", b"1", b"0"):
+    for k, v in fixed:
+        _lib.check(lib.msf2_debug_kernel_choice(k.encode(), v.encode()))
     _lib.check(lib.msf2_debug_kernel_choice(knob, val))
     for _ in range(2):
         m(x)
