@@ -64,6 +64,7 @@ struct Knobs {
     int geom2 = -1;             // "geom2": 0 / 1 forces the 128 x 256 geometry off / on
     int attn_fused_min = 256;   // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken
     bool attn_fused = true;     // "attn_fused": bf16 mode, attention scores kept on chip (one kernel) instead of the two-kernel form
+    bool own_stats = true;      // "own_stats": the small-grid forms of the two-product TCN contraction reduce stage A's partial sums themselves
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -77,6 +78,12 @@ struct Ctx {
     int prec = MSF2_PREC_FP32;
     Knobs k = g_knobs;
 };
+
+// Whether a projection to N columns runs in a small-grid tile form (64-column fp32 tiles / 64-row bf16 tiles): the 128 x 128
+// tiling would give fewer workgroups than the chip has CUs (one utterance per call, the callers' own shape).
+static bool small_grid(const Ctx& c, int N) {
+    return c.k.narrow && (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B < 256 && (N % 128) == 0;
+}
 
 // launch the fp32 or the bf16 build of a contraction
 template <class P>
@@ -104,7 +111,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
     const TimedLaunch timed_(P::NSEG == 2 ? c.st : nullptr, P::NSEG == 2);
     // (the two-product form of the DMA kernel streams the bf16 residual with the operands, reads the column vector
     // with the statistics folded in and writes bf16 only: it needs res16, c1f and out16 without out)
-    if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && a.c1f && a.out16 && !a.out && (EPI != EPI_TCN_G || a.gmul16)))) {
+    if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && (a.c1f || a.stat_part) && a.out16 && !a.out && (EPI != EPI_TCN_G || a.gmul16)))) {
         // One workgroup walks 2 column tiles of its row tile: its ring then prefetches the second tile
         // under the epilogue of the first, while the partner workgroup on the same XCD (other two column
         // tiles) reads the same A rows at the same time, so they are fetched from HBM once.  Walking all
@@ -113,7 +120,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         ProjArgs al = a;
         if constexpr (!P::PAIRED && AMODE == A_PLAIN) {
             // fewer 128-row tiles than CUs (one utterance per call): 64-row tiles, twice the workgroups
-            if (c.k.narrow && (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B < 256 && (a.N % 128) == 0) {
+            if (small_grid(c, a.N)) {
                 typedef DmaGeom<P, 7> G7;
                 dim3 g(cdiv(a.N, G7::BNX), cdiv(c.S, G7::BMX), c.B);
                 al.ncol_loop = 1;
@@ -166,6 +173,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
                 return a.sq_part ? G::TN * 32 : 0;
             }
         }
+        if (a.stat_part) { g_bad_operand = true; return 0; }      // only the small-grid forms reduce the statistics themselves
         if (loop > (int)grid.x) loop = grid.x;
         while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
         al.ncol_loop = loop;
@@ -176,12 +184,13 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
     if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return 0; }     // only the DMA kernel reads the bf16 gate
     if constexpr (AMODE == A_PLAIN && !P::PAIRED) {
         // fp32, fewer 128-wide tiles than CUs (one utterance per call): 64-wide tiles, twice the workgroups
-        if (c.prec != MSF2_PREC_BF16 && (long)grid.x * grid.y * grid.z < 256 && a.N >= 128 && c.k.narrow) {
+        if (c.prec != MSF2_PREC_BF16 && small_grid(c, a.N)) {
             grid.x = cdiv(a.N, 64);
             hipLaunchKernelGGL((gemm_kernel<P, 64>), grid, dim3(256), 0, c.st, a);
             return a.sq_part ? 64 / P::WC : 0;
         }
     }
+    if (a.stat_part) { g_bad_operand = true; return 0; }
     launch_gemm<P>(c, grid, a);
     // the fp32 kernel finishes tiles with the row-major epilogue (64-column wave slabs); the register-staged bf16 one does not
     return (a.sq_part && c.prec != MSF2_PREC_BF16) ? BN / P::WC : 0;
@@ -329,22 +338,31 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
     } else {
         w.t = ar.take<float>(M * C);
     }
-    w.part = ar.take<float>(2L * B * (w.nblk + (1 << MSF2_TCN_DEPTH)));     // (stage A's block count grows with the dilation)
+    w.part = ar.take<float>(2L * B * (4 * w.nblk + (1 << MSF2_TCN_DEPTH) + 4));     // (stage A's block count grows with the dilation; 4x the blocks in its small-grid form)
     w.bstat = ar.take<float>(2L * B);
     return w;
+}
+
+// Frames per thread of a TCN stage A launch.  `full` frames (32 per block) normally; a quarter of that when the launch
+// would give fewer than two blocks per CU (one or two short utterances per call): four times the blocks, each thread
+// re-reading two neighbour rows per 2..4 frames instead of per 8..16 -- from a tensor that then fits the caches.
+static int stage_a_frames_per_thread(const Ctx& c, int full, int rows_per_block) {
+    const long blocks = (long)cdiv(c.S, full * rows_per_block) * c.B;
+    return (c.k.narrow && blocks < 512 && full >= 4) ? full / 4 : full;
 }
 
 // returns the number of partial-sum entries (blocks per utterance) the launch wrote
 static int launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned short* h16, const msf2_tcn_weights& tw, int C, int dil) {
     // frames per thread NIT = 32 / (256 / (C / 8)); a block holds 256 / (C / 8) thread rows of NIT frames, dil apart
-    const int rows_per_block = 256 / (C / 8), nit = 32 / rows_per_block;
+    const int rows_per_block = 256 / (C / 8);
+    const int nit = stage_a_frames_per_thread(c, 32 / rows_per_block, rows_per_block);
     const int nblk = cdiv(cdiv(c.S, nit * dil) * dil, rows_per_block);
     const dim3 grid(nblk, c.B), blk(256);
-    switch (C) {
-        case 512: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<8>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
-        case 256: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<4>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
-        case 128: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<2>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
-        default:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<1>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+    switch (nit) {
+        case 8:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<8>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        case 4:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<4>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        case 2:  hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<2>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
+        default: hipLaunchKernelGGL(tcn_stage_a_bf16_kernel<1>, grid, blk, 0, c.st, h16, tw.dw_w, tw.dw_b, w.t16, w.part, c.S, C, dil); break;
     }
     return nblk;
 }
@@ -368,13 +386,19 @@ static int run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned s
     }
     unsigned short* h16 = w.h16a;
     unsigned short* hn16 = w.h16b;
+    const bool own_stats = c.k.own_stats && small_grid(c, C);
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
         const int nb = launch_stage_a_bf16(c, w, h16, tw, C, 1 << j);
-        launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat, tw.c1, tw.c2, w.c1f, C);
         ProjArgs a = proj_args(nullptr, C, tw.w_gate, C, C, c.S, nullptr, C);
         a.A16 = h16; a.A2_16 = w.t16; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
-        a.bstat = w.bstat; a.c1f = w.c1f; a.res16 = h16; a.ldr = C; a.out16 = hn16;
+        a.res16 = h16; a.ldr = C; a.out16 = hn16;
+        if (own_stats && nb <= 64 * ProjNT<A_PLAIN, EPI_TCN>::STAT_NL) {        // one launch fewer per block where launches are what the block costs
+            a.stat_part = w.part; a.stat_nblk = nb; a.stat_eps = 1e-5f; a.stat_count = (double)c.S * C;
+        } else {
+            launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat, tw.c1, tw.c2, w.c1f, C);
+            a.bstat = w.bstat; a.c1f = w.c1f;
+        }
         if (j == MSF2_TCN_DEPTH - 1) {               // the last block hands g * h to proj_out
             a.gmul16 = w.g16;
             launch_proj<A_PLAIN, EPI_TCN_G>(c, a);
@@ -408,25 +432,33 @@ static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short*
     }
     float* h = w.h0;
     float* hn = w.h1;
+    const bool own_stats = c.k.own_stats && small_grid(c, C);
     for (int j = 0; j < MSF2_TCN_DEPTH; ++j) {
         const msf2_tcn_weights& tw = lw.tcn[j];
         int nb;
         {
             // frames per thread NIT = 32 / (256 / (C / 4)); a block holds 256 / (C / 4) thread rows of NIT frames, dil apart
-            const int dil = 1 << j, rows_per_block = 256 / (C / 4), nit = 32 / rows_per_block;
+            const int dil = 1 << j, rows_per_block = 256 / (C / 4);
+            const int nit = stage_a_frames_per_thread(c, 32 / rows_per_block, rows_per_block);
             nb = cdiv(cdiv(c.S, nit * dil) * dil, rows_per_block);
             const dim3 grid(nb, c.B), blk(256);
-            switch (C) {
-                case 512: hipLaunchKernelGGL(tcn_stage_a_kernel<16>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
-                case 256: hipLaunchKernelGGL(tcn_stage_a_kernel<8>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
-                case 128: hipLaunchKernelGGL(tcn_stage_a_kernel<4>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
-                default:  hipLaunchKernelGGL(tcn_stage_a_kernel<2>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+            switch (nit) {
+                case 16: hipLaunchKernelGGL(tcn_stage_a_kernel<16>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                case 8:  hipLaunchKernelGGL(tcn_stage_a_kernel<8>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                case 4:  hipLaunchKernelGGL(tcn_stage_a_kernel<4>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                case 2:  hipLaunchKernelGGL(tcn_stage_a_kernel<2>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
+                default: hipLaunchKernelGGL(tcn_stage_a_kernel<1>, grid, blk, 0, c.st, h, tw.dw_w, tw.dw_b, w.t, w.part, c.S, C, dil); break;
             }
         }
-        launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat);
         ProjArgs a = proj_args(h, C, tw.w_gate, C, C, c.S, hn, C);
         a.A2 = w.t; a.W2 = tw.w_pw; a.bias = tw.b_gate; a.c1 = tw.c1; a.c2 = tw.c2;
-        a.bstat = w.bstat; a.res = h; a.ldr = C;
+        a.res = h; a.ldr = C;
+        if (own_stats && nb <= 64 * ProjNT<A_PLAIN, EPI_TCN>::STAT_NL) {
+            a.stat_part = w.part; a.stat_nblk = nb; a.stat_eps = 1e-5f; a.stat_count = (double)c.S * C;
+        } else {
+            launch_stats_finalize(c, w.part, nb, (long)c.S * C, 1e-5f, w.bstat);
+            a.bstat = w.bstat;
+        }
         if (j == MSF2_TCN_DEPTH - 1) {               // the last block hands g * h to proj_out
             a.gmul = w.g;
             launch_proj<A_PLAIN, EPI_TCN_G>(c, a);
@@ -647,6 +679,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "no_big")) k.no_big = atoi(value) != 0;
     else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
     else if (!strcmp(name, "narrow")) k.narrow = atoi(value) != 0;
+    else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused")) k.attn_fused = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused_min")) k.attn_fused_min = atoi(value);
     else if (!strcmp(name, "geom3")) { strncpy(k.g3, value, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const typename P::Args arg
     // main loop ended with a barrier: LDS is free
     if constexpr (P::EPI_RM) {
         typename P::template ColVecs<(P::PAIRED ? TN / 2 : TN)> cv;
+        if constexpr (BNT != BN) prob.finish_utt_stats();      // (the small-grid form may reduce the TCN statistics itself)
         prob.template load_colvecs<TN>(prob.n0, wc, lane, cv);
         prob.template fold_colvecs<TN>(cv);
         prob.template epilogue_rm<TM, TN>(acc, wr, wc, lane, smA + wave * 1024, cv);
@@ -356,6 +357,9 @@ struct ProjArgs {
     const unsigned short* res16;   // residual read as bf16 instead of res (same pitch ldr)
     float* sq_part;                // EPI_NORM / EPI_BIAS_RES, row-major epilogue: optional [M][ceil(N / w)] sums of out^2 over the w columns of a wave's slab
     int ncol_loop;                 // DMA kernel: consecutive column tiles one workgroup walks (0 = 1); grid.x shrinks accordingly
+    // EPI_TCN / EPI_TCN_G, small-grid tile forms only (init_tile): the utterance statistics as stage A left them, [B][stat_nblk][2]
+    // partial (sum, sum of squares); the kernel reduces them itself (bstat and c1f null) in the order stats_finalize_kernel does.
+    const float* stat_part;  int stat_nblk;  float stat_eps;  double stat_count;
 };
 
 template <int AMODE, int EPI>
@@ -373,6 +377,48 @@ struct ProjNT {
     static constexpr bool EPI_RM = true;    // the fp32 kernel finishes tiles with epilogue_rm
     Args a;
     int b, s0, n0;
+    float mean_u = 0.f, rstd_u = 1.f;     // utterance statistics reduced by the kernel itself (a.stat_part)
+    // (mean, rstd) of utterance b from stage A's partial sums: what stats_finalize_kernel computes, every wave for itself.
+    // The loads are issued when the tile is set up (ahead of the operand traffic); the reduction runs where the values
+    // are first needed.  At most 64 * STAT_NL partial sums per utterance.
+    static constexpr int STAT_NL = 16;
+    float2 sp[IS_TCN ? STAT_NL : 1];
+    __device__ void load_utt_stats() {
+        if constexpr (IS_TCN) {
+            if (a.stat_part) {
+                const float* p = a.stat_part + (long)b * a.stat_nblk * 2;
+#pragma unroll
+                for (int j = 0; j < STAT_NL; ++j)
+                    sp[j] = *reinterpret_cast<const float2*>(p + 2 * min((int)(threadIdx.x & 63) + 64 * j, a.stat_nblk - 1));
+            }
+        }
+    }
+    __device__ void finish_utt_stats() {
+        if constexpr (IS_TCN) {
+            if (a.stat_part) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int j = 0; j < STAT_NL; ++j)
+                    if ((int)(threadIdx.x & 63) + 64 * j < a.stat_nblk) {
+                        s += (double)sp[j].x;
+                        q += (double)sp[j].y;
+                    }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                const double mean = s / a.stat_count;
+                double var = q / a.stat_count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                mean_u = (float)mean;
+                rstd_u = (float)(1.0 / sqrt(var + (double)a.stat_eps));
+            }
+        }
+    }
+    // utterance statistics of the epilogue: finalized by a kernel before this one (bstat) or reduced here
+    __device__ void utt_stats(float& mean_b, float& rstd_b) const {
+        mean_b = 0.f; rstd_b = 1.f;
+        if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
+        else if (IS_TCN && a.stat_part) { mean_b = mean_u; rstd_b = rstd_u; }
+    }
     __device__ void init(const Args& args) {
         a = args;
         const unsigned t = xcd_remap();       // column tiles of one row tile share the A rows
@@ -390,6 +436,7 @@ struct ProjNT {
         b = rest / gridDim.y;
         s0 = (rest % gridDim.y) * tbm;
         n0 = nt * (a.ncol_loop > 1 ? a.ncol_loop : 1) * tbn;
+        load_utt_stats();
     }
     __device__ int col_tiles_here(int nw) const {      // tiles of nw columns this workgroup walks (DMA kernel)
         const int left = (a.N - n0 + nw - 1) / nw;
@@ -505,8 +552,8 @@ struct ProjNT {
     __device__ void fold_colvecs(ColVecs<(PAIRED ? TN / 2 : TN)>& cv) const {
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float mean_b = 0.f, rstd_b = 1.f;
-        if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
+        float mean_b, rstd_b;
+        utt_stats(mean_b, rstd_b);
 #pragma unroll
         for (int tn = 0; tn < TNE; ++tn) {
             if (!a.bias) cv.bias[tn] = zero4;
@@ -525,8 +572,8 @@ struct ProjNT {
     __device__ void epilogue_rm(f32x16 (&acc)[NSEG][TM][TN], int wr, int wc, int lane, float* stage,
                                 const ColVecs<(PAIRED ? TN / 2 : TN)>& cv, const char* rtile = nullptr,
                                 Hook after_first = Hook()) const {
-        float mean_b = 0.f, rstd_b = 1.f;
-        if (a.bstat) { mean_b = a.bstat[2 * b]; rstd_b = a.bstat[2 * b + 1]; }
+        float mean_b, rstd_b;
+        utt_stats(mean_b, rstd_b);
         constexpr int TNE = PAIRED ? TN / 2 : TN;
         constexpr int NT = TM * TNE;
         constexpr bool ROWSTAT = (EPI == EPI_RS_BIAS_ACT || EPI == EPI_NORM);

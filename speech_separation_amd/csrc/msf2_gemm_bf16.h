@@ -405,13 +405,16 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
     // Per-column vectors of the epilogue are loaded BEFORE the ring starts: a load issued later queues behind
     // every copy the CU has in flight.
     constexpr int TNE = P::PAIRED ? TN / 2 : TN;
-    constexpr bool FOLDED = (P::NSEG == 2);      // the two-product form reads c1 with the utterance statistics folded in
+    // the two-product form reads c1 with the utterance statistics folded in (c1f); the small-grid geometry folds them itself,
+    // from finalized statistics or from the ones it reduced (ProjArgs::stat_part)
+    constexpr bool FOLDED = (P::NSEG == 2) && BIG != 7;
     typedef typename P::template ColVecs<TNE> CV;
     CV cv;
     prob.template load_colvecs<TN, FOLDED>(prob.n0, wc, lane, cv);
 #pragma unroll
     for (int t = 0; t < NST; ++t)
         if (issued < total) issue();
+    if constexpr (BIG == 7) prob.finish_utt_stats();
     prob.template fold_colvecs<TN, FOLDED>(cv);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;

@@ -553,6 +553,39 @@ def test_narrow_tiles_agree_with_wide_tiles(models, golden_dir):
     assert agree >= 40.0 and fid >= 38.0
 
 
+def test_small_grid_forms_reduce_their_own_statistics(models, golden_dir):
+    """With one utterance per call the two-product TCN contraction (64-column fp32 tiles / 64-row bf16 tiles) reduces the
+    partial sums of stage A itself instead of waiting for a finalize kernel (192 launches fewer per forward).  Same
+    summation order, same folding of the statistics into the column vector: the waveforms must be bit-identical to the
+    form with the finalize kernel, in both precisions."""
+    lib = _lib.load()
+    z = np.load(os.path.join(golden_dir, "fwd_full_B1_T32000.npz"))
+    x = torch.from_numpy(z["input"]).to(DEV)
+    m16 = MossFormerHIP(FULL_8K, compute_device=DEV, precision=BF)
+    m16.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(FULL_8K, 0).items()})
+    for name, m in (("fp32", models("full")), ("bf16", m16)):
+        outs = []
+        for own in (b"1", b"0"):
+            _lib.check(lib.msf2_debug_kernel_choice(b"own_stats", own))
+            try:
+                outs.append(torch.stack(m(x), 0))
+            finally:
+                _lib.check(lib.msf2_debug_kernel_choice(None, None))
+        assert torch.isfinite(outs[0]).all(), name
+        assert torch.equal(outs[0], outs[1]), name
+    # a ragged shape: 3 utterances of 1.3 s (fewer than 256 tiles as well), small configuration
+    ms = models("small")
+    xs = torch.from_numpy(synth_batch(3, 10403, seed0=5)).to(DEV)
+    outs = []
+    for own in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(b"own_stats", own))
+        try:
+            outs.append(torch.stack(ms(xs), 0))
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_BF16])
 def test_forward_ignores_workspace_contents(prec):
     """The caller owns the workspace and hands it over uninitialised: results must not depend on what it holds
