@@ -65,6 +65,9 @@ struct Knobs {
     int attn_fused_min = 256;   // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken
     bool attn_fused = true;     // "attn_fused": bf16 mode, attention scores kept on chip (one kernel) instead of the two-kernel form
     bool own_stats = true;      // "own_stats": the small-grid forms of the two-product TCN contraction reduce stage A's partial sums themselves
+    int row128 = 1;             // "row128": 1 = the two-product contraction on whole-line row pieces, one column tile per workgroup; 2 = every
+                                //           projection that reaches the 128 x 128 stream form; 0 = none
+    int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: 512 fp32, 257 bf16)
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -82,7 +85,10 @@ struct Ctx {
 // Whether a projection to N columns runs in a small-grid tile form (64-column fp32 tiles / 64-row bf16 tiles): the 128 x 128
 // tiling would give fewer workgroups than the chip has CUs (one utterance per call, the callers' own shape).
 static bool small_grid(const Ctx& c, int N) {
-    return c.k.narrow && (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B < 256 && (N % 128) == 0;
+    // measured on 4-s utterances, batch 1..4 (128 / 256 / 384 / 512 tiles for N = 512): fp32 faster in the small-grid form up to
+    // 384 tiles (two workgroups per CU: 512 slots), bf16 up to 256
+    const int below = c.k.narrow_below >= 0 ? c.k.narrow_below : (c.prec == MSF2_PREC_BF16 ? 257 : 512);
+    return c.k.narrow && (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B < below && (N % 128) == 0;
 }
 
 // launch the fp32 or the bf16 build of a contraction
@@ -174,6 +180,20 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             }
         }
         if (a.stat_part) { g_bad_operand = true; return 0; }      // only the small-grid forms reduce the statistics themselves
+        if constexpr (!P::PAIRED) {
+            // Whole-line row pieces, one column tile per workgroup: measured at 64 / 16 / 4 x 4 s, the two-product contraction
+            // 6-9 % faster than the stream form (fabric reads 1.33 -> 0.84 GB per launch: the column tiles of a row tile
+            // share their activation pieces in L2); slower below two workgroups per CU (its ring holds one tile ahead).
+            // Single-product projections measure faster in the geometries chosen above.
+            if ((c.k.row128 == 2 || (c.k.row128 == 1 && P::NSEG == 2)) && a.K % 128 == 0 && a.N % 128 == 0 &&
+                (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 512) {
+                typedef DmaGeom<P, 8> G8;
+                dim3 g(cdiv(a.N, G8::BNX), cdiv(c.S, G8::BMX), c.B);
+                al.ncol_loop = 1;
+                hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 8>), g, dim3(G8::THREADS), 0, c.st, al);
+                return a.sq_part ? G8::TN * 32 : 0;
+            }
+        }
         if (loop > (int)grid.x) loop = grid.x;
         while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
         al.ncol_loop = loop;
@@ -679,6 +699,8 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "no_big")) k.no_big = atoi(value) != 0;
     else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
     else if (!strcmp(name, "narrow")) k.narrow = atoi(value) != 0;
+    else if (!strcmp(name, "row128")) k.row128 = atoi(value);
+    else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused")) k.attn_fused = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused_min")) k.attn_fused_min = atoi(value);

@@ -120,6 +120,14 @@ __device__ __forceinline__ bf16x8_t bf_frag(const char* tile, int row, int step,
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// The 128-byte-row image of the global -> LDS kernel's wide-k geometry: [rows][64 k] bf16, 16-byte chunk c of row r at
+// chunk position c ^ ((r >> 1) & 7) (rows are half a bank row apart, so 16 consecutive rows cover 16 distinct slots).
+__device__ __forceinline__ int bf_swz128(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ bf16x8_t bf_frag128(const char* tile, int row, int step, int kh) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 128 + (((2 * step + kh) ^ bf_swz128(row)) << 4));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // whether K segment SEG of P reads its row-contiguous B operand as packed bf16 (P::b_rc16<SEG>() where a problem states it)
 template <class P, int SEG, class = void> struct RcB16 { static constexpr bool V = false; };
 template <class P, int SEG> struct RcB16<P, SEG, decltype((void)P::template b_rc16<SEG>())> { static constexpr bool V = P::template b_rc16<SEG>(); };
@@ -220,11 +228,11 @@ __global__ __launch_bounds__(256, Bf16MinBlocks<P>::V) void gemm_kernel_bf16(con
 template <class P, int BIG> struct DmaGeom;
 template <class P> struct DmaGeom<P, 0> {
     static constexpr int THREADS = 256, WR = P::WR, WC = P::WC, BMX = BM, BNX = BN;
-    static constexpr int TM = BM / (32 * WR), TN = BN / (32 * WC), NWX = P::NW, NST = 4, MINB = 2;
+    static constexpr int TM = BM / (32 * WR), TN = BN / (32 * WC), NWX = P::NW, NST = 4, MINB = 2, ROWB = 64;
 };
 template <class P> struct DmaGeom<P, 1> {
     static constexpr int THREADS = 512, WR = 4, WC = 2, TM = 2, TN = (P::NSEG == 2) ? 2 : 4;
-    static constexpr int BMX = 256, BNX = WC * TN * 32, NWX = BNX, NST = 4, MINB = 1;
+    static constexpr int BMX = 256, BNX = WC * TN * 32, NWX = BNX, NST = 4, MINB = 1, ROWB = 64;
 };
 
 //   BIG = 2: 128 x 256 tile, 4 waves as 2 x 2 (64 x 128 per wave), 3-slot ring (72 KB, the epilogue tiles reuse slot 0 once
@@ -233,20 +241,20 @@ template <class P> struct DmaGeom<P, 1> {
 //            of the other.
 template <class P> struct DmaGeom<P, 2> {
     static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 4;
-    static constexpr int BMX = 128, BNX = 256, NWX = 256, NST = 3, MINB = 2;
+    static constexpr int BMX = 128, BNX = 256, NWX = 256, NST = 3, MINB = 2, ROWB = 64;
 };
 
 //   BIG = 3: 128 x 128 tile, 4 waves, 3-slot ring with the epilogue tiles over slot 0 (48 KB), THREE workgroups per CU
 //            (at most 168 registers per lane).
 template <class P> struct DmaGeom<P, 3> {
     static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 2;
-    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 3, MINB = 3;
+    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 3, MINB = 3, ROWB = 64;
 };
 
 //   BIG = 4: as BIG = 3 with a 2-slot ring (32 KB): FOUR workgroups per CU, at most 128 registers per lane.
 template <class P> struct DmaGeom<P, 4> {
     static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 2;
-    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 2, MINB = 4;
+    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 2, MINB = 4, ROWB = 64;
 };
 
 //   BIG = 7: 64 x 128 tile, 4 waves as 2 x 2 (32 x 64 per wave), 4-slot ring of 12 KB stages, two workgroups per CU.  For
@@ -255,20 +263,35 @@ template <class P> struct DmaGeom<P, 4> {
 //            bf16 residual in the epilogue (no residual tiles in the ring) and keeps both accumulator sets (64 registers).
 template <class P> struct DmaGeom<P, 7> {
     static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 1, TN = 2;
-    static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 4, MINB = 2;
+    static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 4, MINB = 2, ROWB = 64;
+};
+
+//   BIG = 8: 128 x 128 tile, 4 waves, k tiles of 64: row pieces of 128 bytes = whole cache lines (a 64-byte piece makes the
+//            CU's vector cache fetch the whole line from L2, and the other half again one k tile later: L2-resident
+//            operands stream 1.6x faster in whole lines).  32 KB per stage, 2-slot ring, two workgroups per CU; ONE column
+//            tile per workgroup: the column tiles of a row tile are separate workgroups that run side by side on one XCD and
+//            read the same activation pieces at the same time, so the fabric delivers them once.  The two-product form
+//            takes its bf16 residual tile through the ring as the last stage.  K must be a multiple of 64.
+template <class P> struct DmaGeom<P, 8> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 2, TN = 2;
+    static constexpr int BMX = 128, BNX = 128, NWX = 128, NST = 2, MINB = 2, ROWB = 128;
 };
 
 template <class P, int BIG>
 __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
     constexpr bool SMALL = (BIG == 0);                  // the 128 x 128 stream form: several column tiles, both products, residual tiles
-    static_assert(SMALL || BIG == 7 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
+    static_assert(SMALL || BIG == 7 || BIG == 8 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
     static_assert(!P::PAIRED || SMALL, "paired columns: 128 x 128 geometry only");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
-    constexpr int TILE_A = G::BMX * 64, TILE_B = G::BNX * 64, STAGE = TILE_A + TILE_B;   // bytes
-    constexpr int PA = G::BMX / 16 / NWAVES, PB = G::BNX / 16 / NWAVES;                  // copies per wave and k tile: 16 rows x 64 B each
+    constexpr int ROWB = G::ROWB;                       // bytes of a row piece of one k tile: 64 (k tile 32) or 128 (k tile 64)
+    constexpr int KT = ROWB / 2, KTU = KT / BK;         // k per tile; in units of the problem's k-tile argument
+    constexpr int NSUB = ROWB / 32;                     // MFMA steps (k 16) per k tile
+    constexpr int RPI = 1024 / ROWB, LPR = ROWB / 16;   // rows per copy instruction; lanes per row
+    constexpr int TILE_A = G::BMX * ROWB, TILE_B = G::BNX * ROWB, STAGE = TILE_A + TILE_B;   // bytes
+    constexpr int PA = G::BMX / RPI / NWAVES, PB = G::BNX / RPI / NWAVES;                // copies per wave and k tile: 1 KiB each
     constexpr int DMA_PER_TILE = PA + PB;
-    static_assert(PA >= 1 && PB >= 1 && PA * 16 * NWAVES == G::BMX && PB * 16 * NWAVES == G::BNX, "tile rows must split evenly over the waves");
+    static_assert(PA >= 1 && PB >= 1 && PA * RPI * NWAVES == G::BMX && PB * RPI * NWAVES == G::BNX, "tile rows must split evenly over the waves");
     constexpr bool STAGE_IN_RING = (BIG >= 2 && BIG <= 4);    // the epilogue tiles lie over slot 0 (no copy is in flight by then)
     static_assert(!STAGE_IN_RING || NWAVES * 4096 <= STAGE, "the epilogue tiles must fit one ring slot");
     __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + (STAGE_IN_RING ? 0 : NWAVES * 4096)];   // ring (+ one 4 KiB epilogue tile per wave)
@@ -286,10 +309,11 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
     // tiles of each column tile and is read from LDS.  Loaded from global memory by the epilogue itself
     // it queues behind the ~96 KB of operand copies the CU has in flight: those 16 loads cost more
     // cycles than the 32 K steps.
-    constexpr bool RESLDS = SMALL && (P::NSEG == 2);
-    constexpr int NRES = RESLDS ? 2 : 0;
-    static_assert(!RESLDS || (STAGE == 16384 && DMA_PER_TILE * NWAVES == 16), "residual tiles reuse the ring stage and its copy count");
-    const int nk0 = prob.nk(0), nkt = nk0 * P::NSEG, nstream = nkt + NRES;
+    constexpr bool RESLDS = (SMALL || BIG == 8) && (P::NSEG == 2);
+    constexpr int RROWS = STAGE / 256;                  // residual rows (256 B each) one ring stage holds
+    constexpr int NRES = RESLDS ? 128 / RROWS : 0;
+    static_assert(!RESLDS || ((STAGE == 16384 || STAGE == 32768) && DMA_PER_TILE * NWAVES * 1024 == STAGE), "residual tiles reuse the ring stage and its copy count");
+    const int nk0 = prob.nk(0) / KTU, nkt = nk0 * P::NSEG, nstream = nkt + NRES;
     // the 256-row geometry is launched with one column tile per workgroup (walking several gains 4 % from the
     // prefetch across epilogues and loses 20 % to the registers the next tile's column vectors take)
     constexpr bool MULTI = SMALL;
@@ -311,20 +335,21 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
     const unsigned short* bb = nullptr;
     auto derive = [&](int seg, int kt) __attribute__((always_inline)) {
         if constexpr (SADDR) {
-            ba = pf.baseA16(seg, kt);
-            bb = pf.baseB16(seg, kt);
+            ba = pf.baseA16(seg, kt * KTU);
+            bb = pf.baseB16(seg, kt * KTU);
         }
+        auto swz = [](int row) __attribute__((always_inline)) { return ROWB == 128 ? bf_swz128(row) : bf_swz(row); };
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int row = (wave * PA + i) * 16 + (lane >> 2);
-            if constexpr (SADDR) oa[i] = pf.offA16(row, ((lane & 3) ^ bf_swz(row)) * 8);
-            else pa[i] = pf.ptrA16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+            const int row = (wave * PA + i) * RPI + lane / LPR;
+            if constexpr (SADDR) oa[i] = pf.offA16(row, ((lane % LPR) ^ swz(row)) * 8);
+            else pa[i] = pf.ptrA16(seg, kt * KTU, row, ((lane % LPR) ^ swz(row)) * 8);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int row = (wave * PB + i) * 16 + (lane >> 2);
-            if constexpr (SADDR) ob[i] = pf.offB16(row, ((lane & 3) ^ bf_swz(row)) * 8);
-            else pb[i] = pf.ptrB16(seg, kt, row, ((lane & 3) ^ bf_swz(row)) * 8);
+            const int row = (wave * PB + i) * RPI + lane / LPR;
+            if constexpr (SADDR) ob[i] = pf.offB16(row, ((lane % LPR) ^ swz(row)) * 8);
+            else pb[i] = pf.ptrB16(seg, kt * KTU, row, ((lane % LPR) ^ swz(row)) * 8);
         }
     };
     // the copies of one k tile into ring slot `base`, then one k tile further
@@ -339,7 +364,7 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
                 if constexpr (SADDR) dma16_so(ba, oa[i], lds);
                 else dma16(pa[i], lds);
             }
-            if constexpr (!SADDR) pa[i] += BK;
+            if constexpr (!SADDR) pa[i] += KT;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -351,21 +376,21 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
                 if constexpr (SADDR) dma16_so(bb, ob[i], lds);
                 else dma16(pb[i], lds);
             }
-            if constexpr (!SADDR) pb[i] += BK;
+            if constexpr (!SADDR) pb[i] += KT;
         }
-        if constexpr (SADDR) { ba += BK; bb += BK; }
+        if constexpr (SADDR) { ba += KT; bb += KT; }
     };
     auto issue = [&]() __attribute__((always_inline)) {
         char* base = sm + slot(issued) * STAGE;
         if (RESLDS && pf_t >= nkt) {
-            // residual rows 64 r .. 64 r + 63: one copy = 4 rows x 256 B, chunk swizzled on the source side
+            // residual rows RROWS r .. RROWS (r + 1) - 1: one copy = 4 rows x 256 B, chunk swizzled on the source side
             const int r = pf_t - nkt;
 #pragma unroll
             for (int i = 0; i < DMA_PER_TILE; ++i) {
                 const int inst = wave * DMA_PER_TILE + i;
                 const int row = inst * 4 + (lane >> 4);
                 const int chunk = (lane & 15) ^ (row & 7);
-                dma16(pf.ptrRes16(64 * r + row, chunk * 8), __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+                dma16(pf.ptrRes16(RROWS * r + row, chunk * 8), __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
             }
         } else {
             const int seg = (P::NSEG == 2 && pf_t >= nk0) ? 1 : 0;
@@ -437,9 +462,9 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
         if (sa != nullptr) return;      // timing-only build: no fragment reads at all
 #endif
 #pragma unroll
-        for (int q = 0; q < TM; ++q) fa[q] = bf_frag(sa, rowA + q * 32, st, kh);
+        for (int q = 0; q < TM; ++q) fa[q] = ROWB == 128 ? bf_frag128(sa, rowA + q * 32, st, kh) : bf_frag(sa, rowA + q * 32, st, kh);
 #pragma unroll
-        for (int q = 0; q < TN; ++q) fb[q] = bf_frag(sb, rowB + q * 32, st, kh);
+        for (int q = 0; q < TN; ++q) fb[q] = ROWB == 128 ? bf_frag128(sb, rowB + q * 32, st, kh) : bf_frag(sb, rowB + q * 32, st, kh);
     };
     auto mfma_half = [&](const bf16x8_t (&fa)[TM], const bf16x8_t (&fb)[TN], f32x16 (&ac)[TM][TN]) {
 #ifdef MSF2_DIAG_NOMFMA
@@ -464,7 +489,17 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
 #pragma unroll
         for (int q = 0; q < TN; ++q) fb1[q] = fb0[q];
 #else
-        read_half(1, fa1, fb1);
+        if constexpr (NSUB == 4) {          // k tile of 64: two more MFMA steps ahead of the tile switch
+            read_half(1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa0, fb0, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(fa1, fb1, ac);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_half(NSUB - 1, fa1, fb1);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         mfma_half(fa0, fb0, ac);
@@ -545,10 +580,10 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
         const bool more = MULTI && rep + 1 < nrep;
         auto next_vecs = [&]() __attribute__((always_inline)) { if (more) prob.template load_colvecs<TN, FOLDED>(prob.n0 + G::NWX, wc, lane, cvn); };
         if constexpr (RESLDS) {
-            // the two residual tiles are stream tiles cons and cons + 1; wave row wr reads tile cons + wr
-            wait_tile(cons + 1);
+            // the residual tile(s) are stream tiles cons .. cons + NRES - 1, RROWS rows of 256 B each
+            wait_tile(cons + NRES - 1);
             __builtin_amdgcn_s_barrier();
-            prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + slot(cons + (wr * TM) / 2) * STAGE + ((wr * TM) & 1) * (32 * 256), next_vecs);
+            prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + slot(cons + (wr * TM * 32) / RROWS) * STAGE + ((wr * TM * 32) % RROWS) * 256, next_vecs);
             cons += NRES;
 #ifdef MSF2_DIAG_DRAIN_AFTER_EPI
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing-only build: every store acknowledged before the stream goes on

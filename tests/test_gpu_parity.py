@@ -408,7 +408,8 @@ def test_bf16_kernel_choices_agree():
                 ("loop4", {"no_big": "1", "ncol_loop": "4"}),
                 ("geom2_all", {"geom2": "1", "geom3": "n", "geom4": "n"}),
                 ("geom1_all", {"geom2": "0", "geom3": "n", "geom4": "n"}),
-                ("geom3_all", {"geom3": "a0123", "geom4": "n"}), ("geom4_all", {"geom4": "a0123"}))
+                ("geom3_all", {"geom3": "a0123", "geom4": "n"}), ("geom4_all", {"geom4": "a0123"}),
+                ("row128_off", {"row128": "0"}), ("row128_all", {"row128": "2", "no_big": "1"}))
     lib = _lib.load()
     for name, choice in variants:
         _lib.check(lib.msf2_debug_kernel_choice(None, None))

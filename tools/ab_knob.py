@@ -15,7 +15,8 @@ m = MossFormerHIP(cfg, compute_device="cuda:0", precision=prec)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 0).items()})
 x = torch.from_numpy(synth_batch(B, 32000, seed0=0)).to("cuda:0")
 fixed = [kv.split("=") for kv in os.environ.get("AB_FIXED", "").split(",") if kv]     # e.g. AB_FIXED=no_big=1
-for val in (b"1", b"0", b"1", b"0"):
+vals = [v.encode() for v in os.environ.get("AB_VALUES", "1,0,1,0").split(",")]
+for val in vals:
     for k, v in fixed:
         _lib.check(lib.msf2_debug_kernel_choice(k.encode(), v.encode()))
     _lib.check(lib.msf2_debug_kernel_choice(knob, val))
