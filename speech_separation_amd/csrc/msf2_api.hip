@@ -130,6 +130,15 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
                 typedef DmaGeom<P, 7> G7;
                 dim3 g(cdiv(a.N, G7::BNX), cdiv(c.S, G7::BMX), c.B);
                 al.ncol_loop = 1;
+                // at most one workgroup per CU: whole-line row pieces and a deeper ring (one workgroup fills a CU's LDS)
+                if (c.k.row128 && a.K % 128 == 0 && (long)g.x * g.y * g.z <= 256) {
+                    hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 9>), g, dim3(G7::THREADS), 0, c.st, al);
+                    return a.sq_part ? G7::TN * 32 : 0;
+                }
+                if (c.k.row128 && a.K % 128 == 0) {           // (two per CU: the 2-slot ring; 2.5 % at 2 x 4 s)
+                    hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 10>), g, dim3(G7::THREADS), 0, c.st, al);
+                    return a.sq_part ? G7::TN * 32 : 0;
+                }
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 7>), g, dim3(G7::THREADS), 0, c.st, al);
                 return a.sq_part ? G7::TN * 32 : 0;
             }

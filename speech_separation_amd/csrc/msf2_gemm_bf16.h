@@ -266,6 +266,19 @@ template <class P> struct DmaGeom<P, 7> {
     static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 4, MINB = 2, ROWB = 64;
 };
 
+//   BIG = 9: BIG = 7 on whole-line row pieces (k tiles of 64, 24 KB per stage, 4-slot ring): ONE workgroup per CU, for grids of
+//            at most one workgroup per CU, where a CU's copy rate is what a tile costs (72 KB in flight per CU).
+template <class P> struct DmaGeom<P, 9> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 1, TN = 2;
+    static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 4, MINB = 1, ROWB = 128;
+};
+
+//   BIG = 10: BIG = 9 with a 2-slot ring (48 KB): two workgroups per CU.
+template <class P> struct DmaGeom<P, 10> {
+    static constexpr int THREADS = 256, WR = 2, WC = 2, TM = 1, TN = 2;
+    static constexpr int BMX = 64, BNX = 128, NWX = 128, NST = 2, MINB = 2, ROWB = 128;
+};
+
 //   BIG = 8: 128 x 128 tile, 4 waves, k tiles of 64: row pieces of 128 bytes = whole cache lines (a 64-byte piece makes the
 //            CU's vector cache fetch the whole line from L2, and the other half again one k tile later: L2-resident
 //            operands stream 1.6x faster in whole lines).  32 KB per stage, 2-slot ring, two workgroups per CU; ONE column
@@ -281,7 +294,7 @@ template <class P, int BIG>
 __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)) void gemm_kernel_bf16_dma(const typename P::Args args) {
     typedef DmaGeom<P, BIG> G;
     constexpr bool SMALL = (BIG == 0);                  // the 128 x 128 stream form: several column tiles, both products, residual tiles
-    static_assert(SMALL || BIG == 7 || BIG == 8 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
+    static_assert(SMALL || BIG >= 7 || (!P::PAIRED && P::NSEG == 1), "paired-column and two-product problems keep the 128 x 128 geometry");
     static_assert(!P::PAIRED || SMALL, "paired columns: 128 x 128 geometry only");
     constexpr int NST = G::NST, TM = G::TM, TN = G::TN, NWAVES = G::THREADS / 64;
     constexpr int ROWB = G::ROWB;                       // bytes of a row piece of one k tile: 64 (k tile 32) or 128 (k tile 64)
@@ -432,14 +445,14 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
     constexpr int TNE = P::PAIRED ? TN / 2 : TN;
     // the two-product form reads c1 with the utterance statistics folded in (c1f); the small-grid geometry folds them itself,
     // from finalized statistics or from the ones it reduced (ProjArgs::stat_part)
-    constexpr bool FOLDED = (P::NSEG == 2) && BIG != 7;
+    constexpr bool FOLDED = (P::NSEG == 2) && BIG != 7 && BIG != 9 && BIG != 10;
     typedef typename P::template ColVecs<TNE> CV;
     CV cv;
     prob.template load_colvecs<TN, FOLDED>(prob.n0, wc, lane, cv);
 #pragma unroll
     for (int t = 0; t < NST; ++t)
         if (issued < total) issue();
-    if constexpr (BIG == 7) prob.finish_utt_stats();
+    if constexpr (BIG == 7 || BIG == 9 || BIG == 10) prob.finish_utt_stats();
     prob.template fold_colvecs<TN, FOLDED>(cv);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;

@@ -574,6 +574,15 @@ def test_small_grid_forms_reduce_their_own_statistics(models, golden_dir):
                 _lib.check(lib.msf2_debug_kernel_choice(None, None))
         assert torch.isfinite(outs[0]).all(), name
         assert torch.equal(outs[0], outs[1]), name
+    # bf16, one workgroup per CU at most: the 64-row tiles take whole-line row pieces (k tiles of 64) -- same arithmetic
+    outs = []
+    for r128 in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(b"row128", r128))
+        try:
+            outs.append(torch.stack(m16(x), 0))
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    assert torch.equal(outs[0], outs[1])
     # a ragged shape: 3 utterances of 1.3 s (fewer than 256 tiles as well), small configuration
     ms = models("small")
     xs = torch.from_numpy(synth_batch(3, 10403, seed0=5)).to(DEV)
