@@ -22,3 +22,20 @@ cmd="$cmd && timeout -k 10 200 python3 tools/latency_b1.py > $O/latency_b1.jsonl
 cmd="$cmd && timeout -k 10 300 python3 bench.py --recurrent fsmn --no-cpu-baseline > $O/fsmn_fp32_b16_bench.json 2>> $O/cfg.err && timeout -k 10 300 python3 bench.py --recurrent fsmn --precision bf16 --batch 64 --no-cpu-baseline > $O/fsmn_bf16_b64_bench.json 2>> $O/cfg.err"
 timeout 2400 /usr/local/graft/bin/gpurun --timeout 1200 -- "$cmd" 2>&1 | grep -v "every call\|^\[gpurun\] sending"
 ls $O
+# copy what is kept into profiles/ (tracked) and rebuild the traffic record bench.py reads
+V=$(python3 -c "from speech_separation_amd import _lib; print(_lib.load().msf2_version())")
+cp $O/fp32_b16_bench.json profiles/${P}_fp32_b16_bench.json
+cp $O/bf16_b64_bench.json profiles/${P}_bf16_b64_bench.json
+cp $O/fp32_b16_bench_under_rocprof.json profiles/${P}_fp32_b16_bench_under_rocprof.json
+cp $O/bf16_b64_bench_under_rocprof.json profiles/${P}_bf16_b64_bench_under_rocprof.json
+cp $O/prof_fp32/a_kernel_stats.csv profiles/${P}_fp32_b16_bench_kernel_stats.csv
+cp $O/prof_bf16/a_kernel_stats.csv profiles/${P}_bf16_b64_bench_kernel_stats.csv
+cp $O/pmc_fp32_fetch/a_counter_collection.csv profiles/${P}_fp32_tcn_pmc_fetch.csv
+cp $O/pmc_fp32_write/a_counter_collection.csv profiles/${P}_fp32_tcn_pmc_write.csv
+cp $O/pmc_bf16_fetch/a_counter_collection.csv profiles/${P}_bf16_tcn_pmc_fetch.csv
+cp $O/pmc_bf16_write/a_counter_collection.csv profiles/${P}_bf16_tcn_pmc_write.csv
+cat $O/c4_fp32.json $O/c4_bf16.json $O/c5_fp32.json $O/c5_bf16.json > profiles/${P}_c4_c5_one_gpu.jsonl
+cp $O/latency_b1.jsonl profiles/${P}_latency_b1.jsonl
+cat $O/fsmn_fp32_b16_bench.json $O/fsmn_bf16_b64_bench.json > profiles/${P}_fsmn_form_bench.jsonl
+python3 tools/pmc_json.py $P $V > /dev/null
+ls -la profiles/ | grep ${P}_
