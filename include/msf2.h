@@ -188,10 +188,11 @@ int msf2_timing_begin(void);
 int msf2_timing_end(double* total_ms, int* launches);
 
 /* Test aid with no counterpart in the reference: overrides, for the CALLING THREAD only, which of the equivalent
- * kernel geometries the bf16 projections use (every choice performs the same arithmetic in the same order, so
- * results must be bit-identical; the parity tests check exactly that).  name: "ncol_loop", "big_maxn", "no_big",
- * "geom2", "narrow" (integers as text) or "geom3", "geom4" (letters naming projections).  name == NULL restores the
- * defaults.  The library reads no environment variable. */
+ * kernel forms a launch takes (the parity tests compare them: bit-identical, except the bf16 64-row tiles, which agree
+ * with the 128-row ones to bf16 rounding).  name: "ncol_loop", "big_maxn", "no_big", "geom2", "narrow", "narrow_below",
+ * "row128", "own_stats", "attn_fused", "attn_fused_min" (integers as text) or "geom3", "geom4" (letters naming
+ * projections).  name == NULL restores the defaults; an unknown name returns -1.  The library reads no environment
+ * variable. */
 int msf2_debug_kernel_choice(const char* name, const char* value);
 
 /* Frames produced by the encoder for T samples: (T - 16) / 8 + 1. */
