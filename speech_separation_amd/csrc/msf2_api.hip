@@ -519,7 +519,7 @@ static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
     w.t2 = ar.take<float>(M * inner);   w.seq = ar.take<float>(M * inner);
     w.n2 = ar.take<float>(M * inner);
     w.rowstat = ar.take<float>(2 * M);
-    w.part = ar.take<float>(2L * B * w.ntile * inner);
+    w.part = ar.take<float>(2L * B * (w.ntile + 2) * inner);      // (the dilated convolution's tile count rounds up per residue class)
     w.stats = ar.take<float>(2L * B * inner);
     return w;
 }
@@ -557,13 +557,15 @@ static int run_gated_fsmn(const Ctx& c, const FsmnWs& w, const float* x, const m
         ProjArgs a = proj_args(w.f1, C, fw->w_proj, C, C, S, w.p1, C);
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
-    const dim3 cgrid(cdiv(C / 4, 64), w.ntile, B), fgrid(cdiv(C, 256), B);
+    // frame tiles of the two convolutions (dilation 1 and 2): blockIdx.y = tile * dil + residue
+    const int nt1 = cdiv(S, FS_TS), nt2 = cdiv(S, FS_TS * 2) * 2;
+    const dim3 cgrid1(cdiv(C / 2, 64), nt1, B), cgrid2(cdiv(C, 64), nt2, B), fgrid(cdiv(C, 64), B);
     const int egrid = cdiv(M * (C / 4), 256);
-    hipLaunchKernelGGL(fsmn_conv39_kernel<1>, cgrid, dim3(64), 0, c.st, w.p1, (const float*)nullptr, fw->w_c1, w.t1, w.part, S, C, 1);
-    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<1>, cgrid1, dim3(64), 0, c.st, w.p1, (const float*)nullptr, fw->w_c1, w.t1, w.part, S, C, 1);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, nt1, S, C, 1e-5f, w.stats);
     hipLaunchKernelGGL(in_prelu_kernel, dim3(egrid), dim3(256), 0, c.st, w.t1, w.stats, fw->in1_g, fw->in1_b, fw->pr1, w.o1, M, S, C);
-    hipLaunchKernelGGL(fsmn_conv39_kernel<2>, cgrid, dim3(64), 0, c.st, w.o1, w.p1, fw->w_c2, w.t2, w.part, S, C, 2);
-    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, w.ntile, S, C, 1e-5f, w.stats);
+    hipLaunchKernelGGL(fsmn_conv39_kernel<2>, cgrid2, dim3(64), 0, c.st, w.o1, w.p1, fw->w_c2, w.t2, w.part, S, C, 2);
+    hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, nt2, S, C, 1e-5f, w.stats);
     hipLaunchKernelGGL(fsmn_gate_kernel, dim3(egrid), dim3(256), 0, c.st, w.uv, w.t2, w.stats, fw->in2_g, fw->in2_b, fw->pr2, w.n1,
                        w.seq, M, S, C);
     hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f);

@@ -796,20 +796,23 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 //   NIN = 1: depthwise, t[s, c] = sum_k w[k][c] in0[s + (k - 19) dil, c]
 //   NIN = 2: 2 input channels per output channel out of the concatenation [in0 | in1] (C channels each):
 //            t[s, g] = sum_k sum_i w[k][i][g] cat[s + (k - 19) dil, 2 g + i]
-// grid (ceil(C/4 / 64), ceil(S / FS_TS), B), block 64; a thread owns 4 output channels and FS_TS frames.
+// Sliding window in registers: a thread owns one float2 of input channels (NIN = 1: 2 output channels, NIN = 2: the one
+// output channel they feed) and FS_TS output frames that are `dil` apart (s0 + j dil), so the FS_TS + 38 input rows it
+// reads are all it needs: 3.4 row reads per result instead of 39.  The window stays in registers (108); every input row
+// is loaded once from a clamped address (rows outside the utterance are zeroed by a 0/1 factor, never by a predicated
+// load); the taps are read as they are used.
+// grid (ceil(threads over channels / 64), ceil(S / (FS_TS dil)) dil, B), block 64; blockIdx.y = tile * dil + residue.
 // part: [B][gridDim.y][C][2]
-constexpr int FS_TS = 8, FS_K = 39;
+constexpr int FS_TS = 16, FS_K = 39;
 template <int NIN>
-__global__ __launch_bounds__(64) void fsmn_conv39_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
-                                                         const float* __restrict__ w, float* __restrict__ t,
-                                                         float* __restrict__ part, int S, int C, int dil) {
-    const int cq = blockIdx.x * 64 + threadIdx.x;
-    if (cq >= (C >> 2)) return;
-    const int c = 4 * cq, b = blockIdx.z, s0 = blockIdx.y * FS_TS;
-    float4 acc[FS_TS];
-#pragma unroll
-    for (int o = 0; o < FS_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // input channels of this thread: NIN = 1: c..c+3 of in0; NIN = 2: 2c..2c+7 of the concatenation
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void fsmn_conv39_kernel(const float* __restrict__ in0, const float* __restrict__ in1,
+                                                             const float* __restrict__ w, float* __restrict__ t,
+                                                             float* __restrict__ part, int S, int C, int dil) {
+    constexpr int CO = (NIN == 1) ? 2 : 1;                 // output channels per thread
+    const int c = CO * (blockIdx.x * 64 + threadIdx.x);    // first of them
+    if (c >= C) return;
+    const int b = blockIdx.z, s0 = (blockIdx.y / dil) * (FS_TS * dil) + (blockIdx.y % dil);
+    // input channels of this thread: NIN = 1: c, c+1 of in0; NIN = 2: 2c, 2c+1 of the concatenation
     const float* src = in0;
     int cin = c;
     if (NIN == 2) {
@@ -817,54 +820,73 @@ __global__ __launch_bounds__(64) void fsmn_conv39_kernel(const float* __restrict
         if (cin >= C) { src = in1; cin -= C; }
     }
     const float* base = src + (long)b * S * C + cin;
+    // the whole window of this thread: rows s0 + (j - 19) dil, j = 0 .. FS_TS + 37, all requested up front
+    constexpr int NR = FS_TS + FS_K - 1;
+    float2 x[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int s = s0 + (j - FS_K / 2) * dil;
+        x[j] = *reinterpret_cast<const float2*>(base + (long)min(max(s, 0), S - 1) * C);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int s = s0 + (j - FS_K / 2) * dil;
+        const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
+        x[j].x *= inb; x[j].y *= inb;
+    }
+    float2 acc[FS_TS];          // NIN = 2 uses .x only
+#pragma unroll
+    for (int o = 0; o < FS_TS; ++o) acc[o] = make_float2(0.f, 0.f);
+    // tap by tap (the taps of a thread's channels are the same for every frame: cache-resident loads)
+#pragma unroll
     for (int k = 0; k < FS_K; ++k) {
-        float4 w0, w1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NIN == 1) w0 = *reinterpret_cast<const float4*>(w + (long)k * C + c);
-        else {
-            w0 = *reinterpret_cast<const float4*>(w + ((long)k * 2 + 0) * C + c);
-            w1 = *reinterpret_cast<const float4*>(w + ((long)k * 2 + 1) * C + c);
-        }
+        float2 wv;              // NIN = 1: w[k][c .. c+1]; NIN = 2: (w[k][0][c], w[k][1][c])
+        if (NIN == 1) wv = *reinterpret_cast<const float2*>(w + (long)k * C + c);
+        else wv = make_float2(w[((long)k * 2 + 0) * C + c], w[((long)k * 2 + 1) * C + c]);
 #pragma unroll
         for (int o = 0; o < FS_TS; ++o) {
-            const int s = s0 + o + (k - FS_K / 2) * dil;
-            const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
-            const float* row = base + (long)min(max(s, 0), S - 1) * C;
-            if (NIN == 1) {
-                const float4 x = *reinterpret_cast<const float4*>(row);
-                acc[o].x += w0.x * x.x * inb; acc[o].y += w0.y * x.y * inb; acc[o].z += w0.z * x.z * inb; acc[o].w += w0.w * x.w * inb;
-            } else {
-                const float4 xa = *reinterpret_cast<const float4*>(row), xb = *reinterpret_cast<const float4*>(row + 4);
-                acc[o].x += (w0.x * xa.x + w1.x * xa.y) * inb; acc[o].y += (w0.y * xa.z + w1.y * xa.w) * inb;
-                acc[o].z += (w0.z * xb.x + w1.z * xb.y) * inb; acc[o].w += (w0.w * xb.z + w1.w * xb.w) * inb;
-            }
+            if (NIN == 1) { acc[o].x += wv.x * x[o + k].x; acc[o].y += wv.y * x[o + k].y; }
+            else acc[o].x += wv.x * x[o + k].x + wv.y * x[o + k].y;
         }
     }
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
+    float2 sum = make_float2(0.f, 0.f), sq = sum;
 #pragma unroll
     for (int o = 0; o < FS_TS; ++o) {
-        const int s = s0 + o;
+        const int s = s0 + o * dil;
         if (s < S) {
-            *reinterpret_cast<float4*>(t + ((long)b * S + s) * C + c) = acc[o];
-            sum.x += acc[o].x; sum.y += acc[o].y; sum.z += acc[o].z; sum.w += acc[o].w;
-            sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
+            if (NIN == 1) *reinterpret_cast<float2*>(t + ((long)b * S + s) * C + c) = acc[o];
+            else t[((long)b * S + s) * C + c] = acc[o].x;
+            sum.x += acc[o].x; sum.y += acc[o].y;
+            sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y;
         }
     }
     float* pp = part + (((long)b * gridDim.y + blockIdx.y) * C + c) * 2;
-    pp[0] = sum.x; pp[1] = sq.x; pp[2] = sum.y; pp[3] = sq.y; pp[4] = sum.z; pp[5] = sq.z; pp[6] = sum.w; pp[7] = sq.w;
+    pp[0] = sum.x; pp[1] = sq.x;
+    if (NIN == 1) { pp[2] = sum.y; pp[3] = sq.y; }
 }
-// (mean, rstd) per (utterance, channel) from the tile partials.  grid (ceil(C / 256), B), block 256.  stats: [B][C][2]
-__global__ void in_finalize_kernel(const float* __restrict__ part, int ntile, int S, int C, float eps, float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < ntile; ++i) {
-        const float* pp = part + (((long)b * ntile + i) * C + c) * 2;
-        s += (double)pp[0];
-        q += (double)pp[1];
+// (mean, rstd) per (utterance, channel) from the tile partials.  grid (ceil(C / 64), B), block 256: lane = channel,
+// the four waves take every fourth tile each and are summed in wave order.  stats: [B][C][2]
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ part, int ntile, int S, int C, float eps,
+                                                          float* __restrict__ stats) {
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = min(blockIdx.x * 64 + lane, C - 1), b = blockIdx.y;
+    double s = 0.0, sq = 0.0;
+    for (int i = q; i < ntile; i += 4) {
+        const float2 pp = *reinterpret_cast<const float2*>(part + (((long)b * ntile + i) * C + c) * 2);
+        s += (double)pp.x;
+        sq += (double)pp.y;
     }
-    const double mean = s / S, var = fmax(q / S - mean * mean, 0.0);
-    stats[((long)b * C + c) * 2] = (float)mean;
-    stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    red[0][q][lane] = s;
+    red[1][q][lane] = sq;
+    __syncthreads();
+    if (q == 0 && blockIdx.x * 64 + lane < C) {
+        const double st = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        const double qt = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        const double mean = st / S, var = fmax(qt / S - mean * mean, 0.0);
+        stats[((long)b * C + c) * 2] = (float)mean;
+        stats[((long)b * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 __device__ __forceinline__ float in_prelu1(float v, float mean, float rstd, float g, float bta, float slope) {
     const float y = (v - mean) * rstd * g + bta;
