@@ -24,10 +24,12 @@ struct Args {
     const char* w;      // [2][512][PITCH] bytes, weights
     int M;              // rows
     int ncol;           // column tiles a workgroup walks (each re-reads its activation rows)
+    int share;          // > 1: `share` consecutive workgroups take the column tiles of ONE row tile (they read the same activation rows)
+    int pitch;          // bytes from one row to the next (activations and weights)
     unsigned* sink;
 };
 
-constexpr int PITCH = 1024;   // K = 512 bf16
+constexpr int KBYTES = 1024;  // K = 512 bf16
 
 // ROWB: bytes per row piece; NST: ring slots; a slot = 128 activation rows + 128 weight rows of ROWB bytes.
 // SRC: 1 activations only, 2 weights only, 3 both.
@@ -36,10 +38,16 @@ __global__ __launch_bounds__(256, MINB) void copy_rate(Args a) {
     constexpr int TILE = 128 * ROWB, STAGE = 2 * TILE;
     constexpr int RPI = 1024 / ROWB, LPR = ROWB / 16;         // rows per wave instruction, lanes per row
     constexpr int PA = 128 / RPI / 4;                         // copies per wave, operand and k tile
-    constexpr int NKT = PITCH / ROWB;                         // k tiles per product
+    constexpr int NKT = KBYTES / ROWB;                        // k tiles per product
+    const int PITCH = a.pitch;
     extern __shared__ __attribute__((aligned(1024))) char sm[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long row0 = (long)blockIdx.x * 128;
+    // workgroups are dealt round-robin over the 8 XCDs (one L2 each): remap so that consecutive logical ids, hence the
+    // workgroups that share a row tile, run on ONE XCD
+    const unsigned nwg = gridDim.x, L = blockIdx.x, xcd = L & 7, idx = L >> 3, q = nwg >> 3, r = nwg & 7;
+    const unsigned lid = a.share > 1 ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : L;
+    const long row0 = (long)(lid / a.share) * 128;
+    const int col0 = lid % a.share;
     unsigned off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256, MINB) void copy_rate(Args a) {
         const int t = issued % (2 * NKT), col = issued / (2 * NKT);
         const int prod = t / NKT, kt = t % NKT;
         const char* A = (prod ? a.t : a.h) + row0 * PITCH + kt * ROWB;
-        const char* W = a.w + ((long)prod * 512 + (col & 3) * 128) * PITCH + kt * ROWB;
+        const char* W = a.w + ((long)prod * 512 + ((col + col0) & 3) * 128) * PITCH + kt * ROWB;
         char* base = sm + (issued % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -94,7 +102,7 @@ template <int ROWB, int NST, int MINB, int SRC>
 static void run1(const char* name, Args a, int wgs_per_cu_lds_pad) {
     const int lds = NST * 2 * 128 * ROWB + wgs_per_cu_lds_pad;
     CK(hipFuncSetAttribute((const void*)copy_rate<ROWB, NST, MINB, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const int grid = a.M / 128;
+    const int grid = a.M / 128 * a.share;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_rate<ROWB, NST, MINB, SRC>), dim3(grid), dim3(256), lds, 0, a);
@@ -107,15 +115,27 @@ static void run1(const char* name, Args a, int wgs_per_cu_lds_pad) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     const int nsrc = ((SRC & 1) ? 1 : 0) + ((SRC & 2) ? 1 : 0);
-    const double bytes = (double)grid * a.ncol * 2 * PITCH * 128 * nsrc;
+    const double bytes = (double)grid * a.ncol * 2 * KBYTES * 128 * nsrc;
     printf("%-44s lds %6d  %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (2.4 GHz, 256 CUs)\n", name, lds, 1e3 * ms, bytes / ms / 1e9,
            bytes / (ms * 1e-3) / 256 / 2.4e9);
     fflush(stdout);
 }
 
 template <int SRC>
+static void run_shared(Args a) {
+    a.ncol = 1;
+    a.share = 4;
+    printf("-- source: %s, one column tile per workgroup, 4 workgroups per row tile, pitch %d\n", SRC == 3 ? "activations + weights" : SRC == 1 ? "activations only" : "weights only", a.pitch);
+    run1<64, 4, 2, SRC>("64 B pieces, 4 slots x 16 KB, 2 wg/CU", a, 16384);
+    run1<128, 2, 2, SRC>("128 B pieces, 2 slots x 32 KB, 2 wg/CU", a, 16384);
+    run1<128, 4, 1, SRC>("128 B pieces, 4 slots x 32 KB, 1 wg/CU", a, 16384);
+    run1<64, 2, 4, SRC>("64 B pieces, 2 slots x 16 KB, 4 wg/CU", a, 0);
+}
+
+template <int SRC>
 static void run_all(Args a) {
     a.ncol = 2;
+    a.share = 1;
     printf("-- source: %s, 2 column tiles per workgroup\n", SRC == 3 ? "activations + weights" : SRC == 1 ? "activations only" : "weights only");
     run1<64, 4, 2, SRC>("64 B pieces, 4 slots x 16 KB, 2 wg/CU", a, 16384);
     run1<128, 2, 2, SRC>("128 B pieces, 2 slots x 32 KB, 2 wg/CU", a, 16384);
@@ -132,11 +152,21 @@ int main(int argc, char** argv) {
     Args a;
     char *h, *t, *w;
     unsigned* sink;
-    CK(hipMalloc(&h, (size_t)M * PITCH)); CK(hipMalloc(&t, (size_t)M * PITCH)); CK(hipMalloc(&w, 2 * 512 * PITCH));
+    const int MAXP = 1280;
+    CK(hipMalloc(&h, (size_t)M * MAXP)); CK(hipMalloc(&t, (size_t)M * MAXP)); CK(hipMalloc(&w, 2 * 512 * MAXP));
     CK(hipMalloc(&sink, 64));
-    CK(hipMemset(h, 1, (size_t)M * PITCH)); CK(hipMemset(t, 2, (size_t)M * PITCH)); CK(hipMemset(w, 3, 2 * 512 * PITCH));
-    a.h = h; a.t = t; a.w = w; a.M = M; a.sink = sink;
-    printf("rows %d (batch %d x 3999 frames), %d workgroups\n", M, B, M / 128);
+    CK(hipMemset(h, 1, (size_t)M * MAXP)); CK(hipMemset(t, 2, (size_t)M * MAXP)); CK(hipMemset(w, 3, 2 * 512 * MAXP));
+    a.h = h; a.t = t; a.w = w; a.M = M; a.sink = sink; a.pitch = 1024;
+    printf("rows %d (batch %d x 3999 frames), %d row tiles\n", M, B, M / 128);
+    if (argc > 2) {         // the shared-row pattern at several row pitches
+        for (int pitch : {1024, 1152}) {
+            a.pitch = pitch;
+            run_shared<3>(a);
+            run_shared<1>(a);
+            run_shared<2>(a);
+        }
+        return 0;
+    }
     run_all<3>(a);
     run_all<1>(a);
     run_all<2>(a);
