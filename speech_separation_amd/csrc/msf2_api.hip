@@ -506,10 +506,11 @@ static int run_gated_tcn(const Ctx& c, const TcnWs& w, float* x, unsigned short*
 // ---- FSMN-family block (Gated_FSMN_Block_Dilated) ------------------------------------
 struct FsmnWs {
     float *c1, *n1, *uv_pre, *uv, *f1, *p1, *t1, *o1, *t2, *seq, *n2, *rowstat, *part, *stats;
+    unsigned short *n1_16, *uv16, *f1_16, *n2_16;      // bf16 mode: operand images of the tensors the block's contractions read
     int ntile;
 };
-static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
-    FsmnWs w;
+static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner, int prec = MSF2_PREC_FP32) {
+    FsmnWs w = {};
     const long M = (long)B * S;
     w.ntile = cdiv(S, FS_TS);
     w.c1 = ar.take<float>(M * inner);   w.n1 = ar.take<float>(M * inner);
@@ -521,6 +522,10 @@ static FsmnWs fsmn_ws(Arena& ar, int B, int S, int inner) {
     w.rowstat = ar.take<float>(2 * M);
     w.part = ar.take<float>(2L * B * (w.ntile + 2) * inner);      // (the dilated convolution's tile count rounds up per residue class)
     w.stats = ar.take<float>(2L * B * inner);
+    if (prec == MSF2_PREC_BF16) {
+        w.n1_16 = ar.take<unsigned short>(M * inner);   w.uv16 = ar.take<unsigned short>(M * 2 * inner);
+        w.f1_16 = ar.take<unsigned short>(M * inner);   w.n2_16 = ar.take<unsigned short>(M * inner);
+    }
     return w;
 }
 static inline bool fsmn_dims_ok(int dim, int inner) {
@@ -530,31 +535,39 @@ static inline bool fsmn_dims_ok(int dim, int inner) {
 // The contractions follow c.prec (bf16 mode: projection matrices bf16, activations rounded on their way into LDS);
 // everything else is fp32.  y16: optional bf16 image of y; sq_part: optional partial row sums of squares of y
 // (see launch_proj); returns their slab width.
+// x16 (bf16 mode, with the workspace laid out for it): bf16 image of x; the block's contractions then read bf16 images of
+// both operands (written by the kernels that produce the tensors) and stream them global -> LDS.
 static int run_gated_fsmn(const Ctx& c, const FsmnWs& w, const float* x, const msf2_fsmn_weights* fw, float* y, int dim, int inner,
-                          unsigned short* y16 = nullptr, float* sq_part = nullptr) {
+                          unsigned short* y16 = nullptr, float* sq_part = nullptr, const unsigned short* x16 = nullptr) {
+    const bool img = c.prec == MSF2_PREC_BF16 && x16 && w.n1_16;
     const int B = c.B, S = c.S;
     const long M = c.M;
     const int C = inner;
     {   // c1 = PReLU(x W1^T + b1)
         ProjArgs a = proj_args(x, dim, fw->w1, dim, C, S, w.c1, C);
         a.bias = fw->b1; a.act = 4; a.prelu = fw->prelu1;
+        if (img) a.A16 = x16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.c1, fw->ln1_g, fw->ln1_b, w.n1, M, C, 1e-5f);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.c1, fw->ln1_g, fw->ln1_b, w.n1, M, C, 1e-5f,
+                       img ? w.n1_16 : nullptr);
     launch_rowstat<1>(c, w.n1, C, w.rowstat, C, 0, 1e-5f);
     {   // [u | v] = silu(LayerNorm(n1) W^T + b), both FFConvM projections in one contraction
         ProjArgs a = proj_args(w.n1, C, fw->w_uv, C, 2 * C, S, w.uv_pre, 2 * C);
         a.rowstat = w.rowstat; a.c1 = fw->c1_uv; a.c2 = fw->c2_uv; a.act = 1;
+        if (img) a.A16 = w.n1_16;
         launch_proj<A_PLAIN, EPI_NORM>(c, a);
     }
-    launch_dwconv17(c, w.uv_pre, 2 * C, fw->dw_uv, w.uv, 2 * C, 2 * C, 0);
+    launch_dwconv17(c, w.uv_pre, 2 * C, fw->dw_uv, w.uv, 2 * C, 2 * C, 0, img ? w.uv16 : nullptr);
     {   // f1 = relu(u Wl^T + b)
         ProjArgs a = proj_args(w.uv, 2 * C, fw->w_lin, C, C, S, w.f1, C);
         a.bias = fw->b_lin; a.act = 3;
+        if (img) { a.A16 = w.uv16; a.out16 = w.f1_16; }
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     {   // p1 = f1 Wp^T
         ProjArgs a = proj_args(w.f1, C, fw->w_proj, C, C, S, w.p1, C);
+        if (img) a.A16 = w.f1_16;
         launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
     }
     // frame tiles of the two convolutions (dilation 1 and 2): blockIdx.y = tile * dil + residue
@@ -568,9 +581,11 @@ static int run_gated_fsmn(const Ctx& c, const FsmnWs& w, const float* x, const m
     hipLaunchKernelGGL(in_finalize_kernel, fgrid, dim3(256), 0, c.st, w.part, nt2, S, C, 1e-5f, w.stats);
     hipLaunchKernelGGL(fsmn_gate_kernel, dim3(egrid), dim3(256), 0, c.st, w.uv, w.t2, w.stats, fw->in2_g, fw->in2_b, fw->pr2, w.n1,
                        w.seq, M, S, C);
-    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f);
+    hipLaunchKernelGGL(ln_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, c.st, w.seq, fw->ln2_g, fw->ln2_b, w.n2, M, C, 1e-5f,
+                       img ? w.n2_16 : nullptr);
     {   // y = x + n2 W2^T + b2
         ProjArgs a = proj_args(w.n2, C, fw->w2, C, dim, S, y, dim);
+        if (img) a.A16 = w.n2_16;
         a.bias = fw->b2; a.res = x; a.ldr = dim; a.out16 = y16; a.sq_part = sq_part;
         return launch_proj<A_PLAIN, EPI_BIAS_RES>(c, a);
     }
@@ -626,7 +641,7 @@ static FwdWs fwd_ws(Arena& ar, const msf2_config& cfg, int B, int S) {
     w.at = attn_ws(ar, B, S, E);
     w.tc = TcnWs();
     w.fs = FsmnWs();
-    if (cfg.recurrent == MSF2_REC_FSMN) w.fs = fsmn_ws(ar, B, S, cfg.fsmn_inner);
+    if (cfg.recurrent == MSF2_REC_FSMN) w.fs = fsmn_ws(ar, B, S, cfg.fsmn_inner, cfg.precision);
     else w.tc = tcn_ws(ar, B, S, C, cfg.precision);
     return w;
 }
@@ -795,7 +810,7 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         // ---- the recurrent block: GatedTCNBlock, or Gated_FSMN_Block_Dilated in place on x ----
         if (fsmn) {
             if (!lw.fsmn) return MSF2_ERR_ARG;
-            sq_w = run_gated_fsmn(c, w.fs, w.x, lw.fsmn, w.x, C, cfg->fsmn_inner, w.x16, w.sqx);
+            sq_w = run_gated_fsmn(c, w.fs, w.x, lw.fsmn, w.x, C, cfg->fsmn_inner, w.x16, w.sqx, w.x16);
         } else
             sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);
         if (l == 0) copy_tap(c, tp.tcn0, w.x, MC);

@@ -755,8 +755,10 @@ __global__ __launch_bounds__(64) void pit_finalize_kernel(const double* __restri
 // FSMN-family block (Gated_FSMN_Block_Dilated): the kernels beside its projections
 // ===========================================================================
 // ---- LayerNorm over the channels of each row, affine (CLayerNorm): one wave per row, C <= 1024, C % 4 == 0
+// y16: optional bf16 image of y (same pitch) for the contraction that reads it next in bf16 mode
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                      const float* __restrict__ bta, float* __restrict__ y, long M, int C, float eps) {
+                                                      const float* __restrict__ bta, float* __restrict__ y, long M, int C, float eps,
+                                                      unsigned short* __restrict__ y16) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -787,6 +789,12 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
             o.x = (v[i].x - mean) * rstd * gg.x + bb.x; o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
             o.z = (v[i].z - mean) * rstd * gg.z + bb.z; o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
             *reinterpret_cast<float4*>(y + m * C + 4 * q) = o;
+            if (y16) {
+                uint2 h;
+                h.x = pk_bf16_pair(o.x, o.y);
+                h.y = pk_bf16_pair(o.z, o.w);
+                *reinterpret_cast<uint2*>(y16 + m * C + 4 * q) = h;
+            }
         }
     }
 }
