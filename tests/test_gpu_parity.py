@@ -844,6 +844,15 @@ def test_gated_fsmn_block(golden_dir):
             fan = int(np.prod(shp[1:])) if len(shp) > 1 else shp[0]
             Wb[k] = (torch.rand(shp, generator=g) * 2 - 1) / fan ** 0.5
     x = torch.randn(B, S, dim, generator=g)
-    ref = cpu_ref.gated_fsmn_block_dilated(x.double(), {k: v.double() for k, v in Wb.items()})
-    got = ops.gated_fsmn(x.to(DEV), pack_fsmn_block(Wb, DEV))
+    W64 = {k: v.double() for k, v in Wb.items()}
+    ref = cpu_ref.gated_fsmn_block_dilated(x.double(), W64)
+    pkb = pack_fsmn_block(Wb, DEV)
+    got = ops.gated_fsmn(x.to(DEV), pkb)
     assert rel_err(got, ref) <= 2e-5
+    # lengths around the tiling of the 39-tap convolutions (16 frames per thread, frames `dil` apart for the dilated
+    # one): shorter than a window, shorter than a tile, one past a tile, odd
+    for B2, S2 in ((1, 1), (3, 7), (2, 16), (2, 33), (1, 41), (2, 130)):
+        xs = torch.randn(B2, S2, dim, generator=g)
+        ref = cpu_ref.gated_fsmn_block_dilated(xs.double(), W64)
+        got = ops.gated_fsmn(xs.to(DEV), pkb)
+        assert rel_err(got, ref) <= 2e-5, (B2, S2)
