@@ -85,10 +85,18 @@ struct Ctx {
 // Whether a projection to N columns runs in a small-grid tile form (64-column fp32 tiles / 64-row bf16 tiles): the 128 x 128
 // tiling would give fewer workgroups than the chip has CUs (one utterance per call, the callers' own shape).
 static bool small_grid(const Ctx& c, int N) {
+    if (!c.k.narrow || (N % 128) != 0) return false;
+    const long t = (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B;
+    if (c.k.narrow_below >= 0) return t < c.k.narrow_below;
     // measured on 4-s utterances, batch 1..4 (128 / 256 / 384 / 512 tiles for N = 512): fp32 faster in the small-grid form up to
     // 384 tiles (two workgroups per CU: 512 slots), bf16 up to 256
-    const int below = c.k.narrow_below >= 0 ? c.k.narrow_below : (c.prec == MSF2_PREC_BF16 ? 257 : 512);
-    return c.k.narrow && (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B < below && (N % 128) == 0;
+    if (c.prec == MSF2_PREC_BF16) return t < 257;
+    if (t < 512) return true;
+    // fp32, a few rounds of 512 resident tiles: the form whose last round is fuller (544 tiles of the N = 2176 projection at
+    // 1 x 4 s are two rounds of 128-wide tiles, the second nearly empty, but 2.1 rounds of half-size tiles: -2 % per forward)
+    if (t >= 4096) return false;
+    const long wide_idle = cdiv(t, 512) * 512 - t, narrow_idle = (cdiv(2 * t, 512) * 512 - 2 * t) / 2;
+    return narrow_idle + t / 16 < wide_idle;
 }
 
 // launch the fp32 or the bf16 build of a contraction
@@ -211,7 +219,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         return a.sq_part ? DmaGeom<P, 0>::TN * 32 : 0;
     }
     if (EPI == EPI_TCN_G && !a.gmul) { g_bad_operand = true; return 0; }     // only the DMA kernel reads the bf16 gate
-    if constexpr (AMODE == A_PLAIN && !P::PAIRED) {
+    if constexpr (!P::PAIRED) {
         // fp32, fewer 128-wide tiles than CUs (one utterance per call): 64-wide tiles, twice the workgroups
         if (c.prec != MSF2_PREC_BF16 && small_grid(c, a.N)) {
             grid.x = cdiv(a.N, 64);
