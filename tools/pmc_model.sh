@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic: hardware counters of chosen kernels inside the bf16 batch-64 forward (separate rocprofv3 --pmc passes, one
-# counter block each), on ONE GPU box.  usage: tools/pmc_model.sh <out-name> <kernel regex>
-N=$1; RE=$2
+# counter block each), on ONE GPU box.  usage: tools/pmc_model.sh <out-name> <kernel regex> ["<ab_knob.py arguments>"]
+N=$1; RE=$2; ARGS=${3:-"attn_fused 64"}
 cd /root/repo
 O=/root/repo/gpurun_out/$N
 PASSES=(
@@ -14,7 +14,7 @@ PASSES=(
 cmd="mkdir -p $O && cd /tmp && export TMPDIR=/tmp && export AB_VALUES=1 && (rocprofv3 -L > $O/avail.txt 2>&1 || true)"
 i=0
 for p in "${PASSES[@]}"; do
-  cmd="$cmd && timeout -s KILL 240 rocprofv3 --pmc $p --kernel-include-regex '$RE' --output-format csv -d $O/p$i -o a -- python3 /root/repo/tools/ab_knob.py attn_fused 64 > $O/p$i.out 2>&1"
+  cmd="$cmd && timeout -s KILL 240 rocprofv3 --pmc $p --kernel-include-regex '$RE' --output-format csv -d $O/p$i -o a -- python3 /root/repo/tools/ab_knob.py $ARGS > $O/p$i.out 2>&1"
   i=$((i+1))
 done
 timeout 2400 /usr/local/graft/bin/gpurun --timeout 1200 -- "$cmd" 2>&1 | grep -v "every call\|^\[gpurun\] sending"
