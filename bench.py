@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra records the default single-GPU fp32 run appends (bf16 batch 64, batch-1 latency)")
+    ap.add_argument("--collectives-at-one-rank", action="store_true",
+                    help="rehearsal on a one-GPU box: form the process group (RCCL) with a single rank and run every collective "
+                         "of the multi-rank path (barriers, output gather, time gather / reduce) exactly as N > 1 ranks do")
     ap.add_argument("--stub-cpu", action="store_true",
                     help="control-flow rehearsal without a GPU: gloo backend, CPU tensors and a trivial stand-in for the "
                          "model (checks launching, collectives per rank and the JSON line; measures nothing)")
@@ -206,8 +209,10 @@ def run_rank(a):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = lambda: torch.cuda.synchronize(dev)                    # noqa: E731
-    if world > 1:
+    use_dist = world > 1 or a.collectives_at_one_rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if stub:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -231,19 +236,19 @@ def run_rank(a):
         model.eval()
         x = torch.from_numpy(synth_batch(B, T, seed0=rank * B)).to(dev)
 
-    gathered = torch.empty((world * cfg.num_spks, B, T), device=dev) if world > 1 else None     # rank-major concatenation
+    gathered = torch.empty((world * cfg.num_spks, B, T), device=dev) if use_dist else None     # rank-major concatenation
     collectives = [0]
 
     def step():
         out = torch.stack(model(x), 0)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out)      # every rank ends a step holding all separated waveforms
             collectives[0] += 1
         return out
 
     def fence():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             collectives[0] += 1
         sync()
@@ -259,7 +264,7 @@ def run_rank(a):
 
     # per-rank times (every rank joins), the job's time is the slowest rank's
     t = torch.tensor([dt_mine], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         allt = torch.empty(world, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(allt, t)
         collectives[0] += 1
@@ -285,7 +290,7 @@ def run_rank(a):
         sync()
         e2e_mine = (time.perf_counter() - t0) / e2e_steps
     t = torch.tensor([e2e_mine], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         collectives[0] += 1
     e2e = float(t.item())
@@ -309,8 +314,8 @@ def run_rank(a):
                                + ("" if a.recurrent == "tcn" else ", Gated_FSMN_Block_Dilated as the recurrent block"),
                    "batch_per_gpu": B, "samples": T, "layers": cfg.num_layers, "dim": cfg.dim,
                    "parallelism": f"utterance-sharded x{world}"},
-        "world_size_seen": dist.get_world_size() if world > 1 else 1,
-        "backend": (dist.get_backend() if world > 1 else None),
+        "world_size_seen": dist.get_world_size() if use_dist else 1,
+        "backend": (dist.get_backend() if use_dist else None),
         "ms_per_step_per_rank": [1e3 * v / a.steps for v in per_rank],
         # inputs resident in HBM ("value") vs. host waveforms in, host waveforms out
         "value_incl_host_copies": audio_s_step / e2e,
@@ -319,6 +324,9 @@ def run_rank(a):
     }
     if stub:
         res["stub"] = True
+        res["collectives_per_rank"] = collectives[0]
+    if a.collectives_at_one_rank:
+        res["rehearsal"] = "process group formed with one rank; every collective of the multi-rank path executed"
         res["collectives_per_rank"] = collectives[0]
 
     if rank == 0 and not stub:
@@ -388,7 +396,7 @@ def run_rank(a):
             res["secondary"] = secondary_bf16(cfg, sd, dev, T, a.seconds, refn0)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

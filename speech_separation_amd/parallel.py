@@ -55,7 +55,7 @@ def assign_items(items, world):
 
 
 def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device="cpu",
-                     references=None, gather=True, max_samples=LIBRARY_MAX_SAMPLES):
+                     references=None, gather=True, max_samples=LIBRARY_MAX_SAMPLES, collectives_at_one_rank=False):
     """Separate a list of 1-D float32 utterances, sharded over ``world`` ranks.
 
     model_fn(x[B, T] tensor on device) -> list of num_spks tensors [B, T].
@@ -63,7 +63,10 @@ def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device
     is a list (per utterance) of arrays [num_spks, T]; elsewhere None.
     stats = (sum, sum_sq, count) of best-permutation SI-SDR over all ranks when
     ``references`` (list of (s1, s2)) is given, else None.
+    collectives_at_one_rank: with world == 1 and an initialised process group, run the reduction and the gather anyway
+    (a one-GPU rehearsal of what N > 1 ranks execute).
     """
+    use_dist = world > 1 or (collectives_at_one_rank and dist.is_initialized())
     from .synth import permute_si_sdr
     lengths = [len(u) for u in utterances]
     plan = assign_items(make_work_items(lengths, max_batch, max_samples), world)
@@ -96,11 +99,11 @@ def separate_sharded(model_fn, utterances, rank=0, world=1, max_batch=16, device
                 v = permute_si_sdr(e[0], e[1], references[i][0], references[i][1])
                 acc += (v, v * v, 1.0)
         t = torch.tensor(acc, dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         stats = tuple(float(v) for v in t.cpu())
 
-    if world == 1:
+    if not use_dist:
         return [local[i].detach().cpu().numpy() for i in range(len(utterances))], stats
     if not gather:
         return None, stats
