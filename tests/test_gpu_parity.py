@@ -240,6 +240,33 @@ def test_fsmn_form_taps_and_full_width(models, golden_dir):
             assert min(fid) >= 30.0
 
 
+def test_full_width_taps_against_oracle():
+    """Where a difference would come from, at the reference's real widths (dim 512; 2 layers, 2 x 2 s): every tap of
+    the forward (encoder, mask-net input, first FLASH block, first gated TCN block, final norms, both masks) against
+    the fp64 oracle -- fp32 mode to 3e-5 relative, bf16 mode to better than 35 dB per tap."""
+    from speech_separation_amd.config import MossFormer2Config
+    cfg = MossFormer2Config(num_layers=2)
+    sd = make_state_dict(cfg, 0)
+    x = torch.from_numpy(synth_batch(2, 16000, seed0=8))
+    ref_taps = {}
+    with torch.no_grad():
+        ref = torch.stack(cpu_ref.forward(cpu_ref.to_torch(sd, torch.float64), x.double(), cfg, taps=ref_taps), 0)
+    names = ("enc", "x0", "flash0", "tcn0", "mdl", "mask0", "mask1")
+    for prec in (_lib.PREC_FP32, BF):
+        m = MossFormerHIP(cfg, compute_device=DEV, precision=prec)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        taps = {}
+        got = torch.stack(m(x.to(DEV), taps=taps), 0).cpu()
+        for name in names:
+            e = rel_err(taps[name], ref_taps[name])
+            print(f"full-width tap {name}, precision {prec}: max-abs error {e:.2e} of the tap's peak")
+            if prec == _lib.PREC_FP32:
+                assert e <= 3e-5, name
+            else:
+                assert e <= 10 ** (-35 / 20), (name, e)
+        assert rel_err(got, ref) <= (3e-5 if prec == _lib.PREC_FP32 else 10 ** (-30 / 20))
+
+
 def test_full_model_matches_reference(models, golden_dir):
     z = np.load(os.path.join(golden_dir, "fwd_full_B1_T32000.npz"))
     out = models("full")(torch.from_numpy(z["input"]).to(DEV))
