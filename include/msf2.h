@@ -189,7 +189,7 @@ int msf2_timing_end(double* total_ms, int* launches);
 
 /* Test aid with no counterpart in the reference: overrides, for the CALLING THREAD only, which of the equivalent
  * kernel forms a launch takes (the parity tests compare them: bit-identical, except the bf16 64-row tiles, which agree
- * with the 128-row ones to bf16 rounding).  name: "ncol_loop", "big_maxn", "no_big", "geom2", "narrow", "narrow_below",
+ * with the 128-row ones to bf16 rounding).  name: "ncol_loop", "big_maxn", "no_big", "geom2", "narrow", "narrow_below", "many_min",
  * "row128", "own_stats", "attn_fused", "attn_fused_min" (integers as text) or "geom3", "geom4" (letters naming
  * projections).  name == NULL restores the defaults; an unknown name returns -1.  The library reads no environment
  * variable. */

@@ -65,6 +65,7 @@ struct Knobs {
     int attn_fused_min = 256;   // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken
     bool attn_fused = true;     // "attn_fused": bf16 mode, attention scores kept on chip (one kernel) instead of the two-kernel form
     bool own_stats = true;      // "own_stats": the small-grid forms of the two-product TCN contraction reduce stage A's partial sums themselves
+    int many_min = 512;         // "many_min": fewest 128 x 128 tiles for which the 3- / 4-workgroup geometries are taken
     int row128 = 1;             // "row128": 1 = the two-product contraction on whole-line row pieces, one column tile per workgroup; 2 = every
                                 //           projection that reaches the 128 x 128 stream form; 0 = none
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: 512 fp32, 257 bf16)
@@ -168,7 +169,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             const char* g3 = c.k.g3;
             const char* g4 = c.k.g4;
             const char key = (AMODE ? 'a' : '0') + EPI;
-            const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 1024;
+            const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= c.k.many_min;
             if (want && many && strchr(g4, key)) {
                 typedef DmaGeom<P, 4> G4;
                 dim3 g(cdiv(a.N, G4::BNX), cdiv(c.S, G4::BMX), c.B);
@@ -734,6 +735,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "geom2")) k.geom2 = atoi(value);
     else if (!strcmp(name, "narrow")) k.narrow = atoi(value) != 0;
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
+    else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused")) k.attn_fused = atoi(value) != 0;
