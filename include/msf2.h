@@ -186,6 +186,13 @@ int msf2_sizeof(int which);
  * threads meanwhile are not recorded.  Keep it off inside a timed region. */
 int msf2_timing_begin(void);
 int msf2_timing_end(double* total_ms, int* launches);
+/* The same timer on a chosen kernel: MSF2_TIMED_TCN_POINTWISE (what msf2_timing_begin selects), or
+ * MSF2_TIMED_HIDDEN_PROJ = the token-shifted to_hidden | to_qk projection of a FLASH layer
+ * (FFConvM.forward, mossformer2_block.py:79-100 after the shift of :245-248), one launch per layer: the kernel that
+ * dominates the forward when the recurrent block is the FSMN-family one.  Any other value returns -1. */
+#define MSF2_TIMED_TCN_POINTWISE 0
+#define MSF2_TIMED_HIDDEN_PROJ 1
+int msf2_timing_begin_kernel(int which);
 
 /* Test aid with no counterpart in the reference: overrides, for the CALLING THREAD only, which of the equivalent
  * kernel forms a launch takes (the parity tests compare them: bit-identical, except the bf16 64-row tiles, which agree
@@ -309,7 +316,9 @@ size_t msf2_pit_si_snr_ws_bytes(int B, int T);
  *   the array is shared by all calls on one GPU: calls that overlap on the same GPU (two streams, two host
  *   threads) race on it -- serialise them, or use msf2_pit_si_snr with a workspace per call;
  *   the first call on a device looks up the array's device address (no allocation); make that call outside
- *   a graph capture.
+ *   a graph capture;
+ *   est and src must be device memory of the calling thread's CURRENT device (the one `stream` belongs to): the
+ *   array used is that device's, and operands living elsewhere are refused with MSF2_ERR_ARG.
  */
 #define MSF2_PIT_NOALLOC_MAX_BLOCKS 8192
 int msf2_pit_si_snr_noalloc(const float* est, const float* src, float* si_snr, float* best, int* perm, int B, int T,

@@ -16,6 +16,8 @@ QK_DIM = 128
 GROUP = 256
 PREC_FP32 = 0
 PREC_BF16 = 1
+TIMED_TCN_POINTWISE = 0   # msf2_timing_begin_kernel: the two-product contraction of a TCN block
+TIMED_HIDDEN_PROJ = 1     # ... the token-shifted to_hidden | to_qk projection of a FLASH layer
 REC_TCN = 0      # GatedTCNBlock after each FLASH layer (what the reference revision instantiates)
 REC_FSMN = 1     # Gated_FSMN_Block_Dilated (the upstream architecture's block, present in the reference)
 
@@ -68,6 +70,7 @@ SYMBOLS = {
     "msf2_version": (_i, []),
     "msf2_sizeof": (_i, [_i]),
     "msf2_timing_begin": (_i, []),
+    "msf2_timing_begin_kernel": (_i, [_i]),
     "msf2_timing_end": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "msf2_debug_kernel_choice": (_i, [C.c_char_p, C.c_char_p]),
     "msf2_num_frames": (_i, [_i]),

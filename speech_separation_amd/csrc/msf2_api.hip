@@ -27,6 +27,7 @@ thread_local bool g_bad_operand = false;
 struct KernelTimer {
     std::mutex mu;
     std::atomic<bool> on{false};
+    std::atomic<int> which{0};          // MSF2_TIMED_*: the kernel whose launches are bracketed
     std::thread::id owner;
     std::vector<hipEvent_t> ev;
 };
@@ -48,6 +49,20 @@ struct TimedLaunch {
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Compute units of the calling thread's current device, asked once per device.  Every grid-size threshold below (which
+// tile form fills the chip) is stated in multiples of it; 256 on MI355X, which is also the fallback if the query fails.
+static int device_cus() {
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cached[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
 static inline bool dim_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
 // the kernels address activation buffers with 32-bit byte offsets: rows * row pitch * 4 must stay below 4 GiB
 static inline bool fits32(long rows, long ld) { return rows * ld * 4 < (1L << 32); }
@@ -62,13 +77,13 @@ struct Knobs {
     int big_maxn = 4096;        // "big_maxn": widest projection that may leave that form
     bool no_big = false;        // "no_big": 128 x 128 stream form only
     int geom2 = -1;             // "geom2": 0 / 1 forces the 128 x 256 geometry off / on
-    int attn_fused_min = 256;   // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken
+    int attn_fused_min = -1;    // "attn_fused_min": fewest workgroups (2 per group and utterance) for which the fused form is taken (-1: one per CU)
     bool attn_fused = true;     // "attn_fused": bf16 mode, attention scores kept on chip (one kernel) instead of the two-kernel form
     bool own_stats = true;      // "own_stats": the small-grid forms of the two-product TCN contraction reduce stage A's partial sums themselves
-    int many_min = 512;         // "many_min": fewest 128 x 128 tiles for which the 3- / 4-workgroup geometries are taken
+    int many_min = -1;          // "many_min": fewest 128 x 128 tiles for which the 3- / 4-workgroup geometries are taken (-1: two per CU)
     int row128 = 1;             // "row128": 1 = the two-product contraction on whole-line row pieces, one column tile per workgroup; 2 = every
                                 //           projection that reaches the 128 x 128 stream form; 0 = none
-    int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: 512 fp32, 257 bf16)
+    int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -81,6 +96,7 @@ struct Ctx {
     long M;
     int prec = MSF2_PREC_FP32;
     Knobs k = g_knobs;
+    int cus = device_cus();     // compute units of the device the launches go to
 };
 
 // Whether a projection to N columns runs in a small-grid tile form (64-column fp32 tiles / 64-row bf16 tiles): the 128 x 128
@@ -91,12 +107,13 @@ static bool small_grid(const Ctx& c, int N) {
     if (c.k.narrow_below >= 0) return t < c.k.narrow_below;
     // measured on 4-s utterances, batch 1..4 (128 / 256 / 384 / 512 tiles for N = 512): fp32 faster in the small-grid form up to
     // 384 tiles (two workgroups per CU: 512 slots), bf16 up to 256
-    if (c.prec == MSF2_PREC_BF16) return t < 257;
-    if (t < 512) return true;
+    if (c.prec == MSF2_PREC_BF16) return t < c.cus + 1;
+    const long round = 2L * c.cus;       // resident 128 x 128 fp32 tiles: two workgroups per CU
+    if (t < round) return true;
     // fp32, a few rounds of 512 resident tiles: the form whose last round is fuller (544 tiles of the N = 2176 projection at
     // 1 x 4 s are two rounds of 128-wide tiles, the second nearly empty, but 2.1 rounds of half-size tiles: -2 % per forward)
-    if (t >= 4096) return false;
-    const long wide_idle = cdiv(t, 512) * 512 - t, narrow_idle = (cdiv(2 * t, 512) * 512 - 2 * t) / 2;
+    if (t >= 8 * round) return false;
+    const long wide_idle = cdiv(t, round) * round - t, narrow_idle = (cdiv(2 * t, round) * round - 2 * t) / 2;
     return narrow_idle + t / 16 < wide_idle;
 }
 
@@ -123,7 +140,8 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         g_bad_operand = true;
         return 0;
     }
-    const TimedLaunch timed_(P::NSEG == 2 ? c.st : nullptr, P::NSEG == 2);
+    constexpr int timed_id = P::NSEG == 2 ? MSF2_TIMED_TCN_POINTWISE : (AMODE == A_SHIFT ? MSF2_TIMED_HIDDEN_PROJ : -1);
+    const TimedLaunch timed_(c.st, timed_id >= 0 && timed_id == g_timer.which.load(std::memory_order_relaxed));
     // (the two-product form of the DMA kernel streams the bf16 residual with the operands, reads the column vector
     // with the statistics folded in and writes bf16 only: it needs res16, c1f and out16 without out)
     if (c.prec == MSF2_PREC_BF16 && a.A16 && (AMODE != A_SHIFT || (a.K % (2 * BK) == 0 && a.K <= 2048)) && (P::NSEG == 1 || (a.A2_16 && a.res16 && (a.c1f || a.stat_part) && a.out16 && !a.out && (EPI != EPI_TCN_G || a.gmul16)))) {
@@ -140,7 +158,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
                 dim3 g(cdiv(a.N, G7::BNX), cdiv(c.S, G7::BMX), c.B);
                 al.ncol_loop = 1;
                 // at most one workgroup per CU: whole-line row pieces and a deeper ring (one workgroup fills a CU's LDS)
-                if (c.k.row128 && a.K % 128 == 0 && (long)g.x * g.y * g.z <= 256) {
+                if (c.k.row128 && a.K % 128 == 0 && (long)g.x * g.y * g.z <= c.cus) {
                     hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 9>), g, dim3(G7::THREADS), 0, c.st, al);
                     return a.sq_part ? G7::TN * 32 : 0;
                 }
@@ -169,7 +187,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             const char* g3 = c.k.g3;
             const char* g4 = c.k.g4;
             const char key = (AMODE ? 'a' : '0') + EPI;
-            const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= c.k.many_min;
+            const bool many = (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= (c.k.many_min >= 0 ? c.k.many_min : 2 * c.cus);
             if (want && many && strchr(g4, key)) {
                 typedef DmaGeom<P, 4> G4;
                 dim3 g(cdiv(a.N, G4::BNX), cdiv(c.S, G4::BMX), c.B);
@@ -184,14 +202,14 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 3>), g, dim3(G3::THREADS), 0, c.st, al);
                 return a.sq_part ? G3::TN * 32 : 0;
             }
-            if (want && geom2 && (long)cdiv(a.N, 256) * cdiv(c.S, 128) * c.B >= 1024) {
+            if (want && geom2 && (long)cdiv(a.N, 256) * cdiv(c.S, 128) * c.B >= 4 * c.cus) {
                 typedef DmaGeom<P, 2> G2;
                 dim3 g2(cdiv(a.N, G2::BNX), cdiv(c.S, G2::BMX), c.B);
                 al.ncol_loop = 1;
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 2>), g2, dim3(G2::THREADS), 0, c.st, al);
                 return a.sq_part ? G2::TN * 32 : 0;
             }
-            if (want && (long)gb.x * gb.y * gb.z >= 1024) {
+            if (want && (long)gb.x * gb.y * gb.z >= 4 * c.cus) {
                 al.ncol_loop = 1;                 // 256 columns per tile already
                 hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 1>), gb, dim3(G::THREADS), 0, c.st, al);
                 return a.sq_part ? G::TN * 32 : 0;
@@ -204,7 +222,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             // share their activation pieces in L2); slower below two workgroups per CU (its ring holds one tile ahead).
             // Single-product projections measure faster in the geometries chosen above.
             if ((c.k.row128 == 2 || (c.k.row128 == 1 && P::NSEG == 2)) && a.K % 128 == 0 && a.N % 128 == 0 &&
-                (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 512) {
+                (long)cdiv(a.N, 128) * cdiv(c.S, 128) * c.B >= 2 * c.cus) {
                 typedef DmaGeom<P, 8> G8;
                 dim3 g(cdiv(a.N, G8::BNX), cdiv(c.S, G8::BMX), c.B);
                 al.ncol_loop = 1;
@@ -213,7 +231,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             }
         }
         if (loop > (int)grid.x) loop = grid.x;
-        while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 1024) loop = (loop + 1) / 2;
+        while (loop > 1 && (long)cdiv(grid.x, loop) * grid.y * grid.z < 4 * c.cus) loop = (loop + 1) / 2;
         al.ncol_loop = loop;
         grid.x = cdiv(grid.x, loop);
         hipLaunchKernelGGL((gemm_kernel_bf16_dma<P, 0>), grid, dim3(256), 0, c.st, al);
@@ -322,7 +340,7 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
         const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
     }
-    if (hu16 && c.k.attn_fused && (E % 64) == 0 && 2L * c.B * w.G >= c.k.attn_fused_min) {
+    if (hu16 && c.k.attn_fused && (E % 64) == 0 && 2L * c.B * w.G >= (c.k.attn_fused_min >= 0 ? c.k.attn_fused_min : c.cus)) {
         // bf16 mode: scores, both products and the gating in one kernel; the scores never leave the chip
         // (one workgroup per half group and CU: below about one workgroup per CU the two-kernel form, whose
         // grid is E / 64 times larger, fills the chip better -- measured equal at 256 workgroups, 6 % slower at 128)
@@ -386,7 +404,7 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
 // re-reading two neighbour rows per 2..4 frames instead of per 8..16 -- from a tensor that then fits the caches.
 static int stage_a_frames_per_thread(const Ctx& c, int full, int rows_per_block) {
     const long blocks = (long)cdiv(c.S, full * rows_per_block) * c.B;
-    return (c.k.narrow && blocks < 512 && full >= 4) ? full / 4 : full;
+    return (c.k.narrow && blocks < 2 * c.cus && full >= 4) ? full / 4 : full;
 }
 
 // returns the number of partial-sum entries (blocks per utterance) the launch wrote
@@ -696,14 +714,17 @@ int msf2_sizeof(int which) {
         default: return -1;
     }
 }
-int msf2_timing_begin(void) {
+int msf2_timing_begin_kernel(int which) {
+    if (which != MSF2_TIMED_TCN_POINTWISE && which != MSF2_TIMED_HIDDEN_PROJ) return MSF2_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_timer.mu);
     for (hipEvent_t e : g_timer.ev) hipEventDestroy(e);
     g_timer.ev.clear();
     g_timer.owner = std::this_thread::get_id();
+    g_timer.which.store(which);
     g_timer.on.store(true);
     return MSF2_OK;
 }
+int msf2_timing_begin(void) { return msf2_timing_begin_kernel(MSF2_TIMED_TCN_POINTWISE); }
 int msf2_timing_end(double* total_ms, int* launches) {
     std::vector<hipEvent_t> ev;
     {
@@ -760,6 +781,9 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
     int rc = check_cfg(cfg);
     if (rc != MSF2_OK) return rc;
     if (!wt || !mix || !out || !workspace || B < 1 || T < 16 || (cfg->num_layers > 0 && !wt->layers)) return MSF2_ERR_ARG;
+    if (cfg->recurrent == MSF2_REC_FSMN)          // checked before the first launch: nothing is enqueued for a bad weight set
+        for (int l = 0; l < cfg->num_layers; ++l)
+            if (!wt->layers[l].fsmn) return MSF2_ERR_ARG;
     const int C = cfg->dim, E = 2 * C, NH = 4 * C + MSF2_QK_DIM, S = msf2_num_frames(T);
     if (!fits32((long)B * S, NH)) return MSF2_ERR_ARG;
     Arena ar(workspace, workspace_bytes);
@@ -819,7 +843,6 @@ int msf2_forward(const msf2_config* cfg, const msf2_weights* wt, const float* mi
         if (l == 0) copy_tap(c, tp.flash0, w.x, MC);
         // ---- the recurrent block: GatedTCNBlock, or Gated_FSMN_Block_Dilated in place on x ----
         if (fsmn) {
-            if (!lw.fsmn) return MSF2_ERR_ARG;
             sq_w = run_gated_fsmn(c, w.fs, w.x, lw.fsmn, w.x, C, cfg->fsmn_inner, w.x16, w.sqx, w.x16);
         } else
             sq_w = run_gated_tcn(c, w.tc, w.x, w.x16, lw, C, have_ln, w.sqx);
@@ -1020,9 +1043,18 @@ constexpr int MAX_DEVICES = 64;
 static std::mutex g_scratch_mu;
 static double* g_scratch_ptr[MAX_DEVICES] = {};
 
-static int scratch_for_current_device(double** out) {
+// The array of the device that owns `ptr` (the kernels run where their operands live).  The calling thread's current
+// device must be that device: the launches below go to `stream`, which HIP requires to belong to the current device, and
+// hipGetSymbolAddress answers for the current device.  A mismatch is refused rather than written to another GPU's array.
+static int scratch_for_operands(const void* ptr, double** out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return MSF2_ERR_ARG;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return MSF2_ERR_ARG;                       // not a pointer HIP knows (host memory that was never registered)
+    }
+    if (attr.type != hipMemoryTypeDevice || attr.device != dev) return MSF2_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         double* p = nullptr;
@@ -1043,7 +1075,10 @@ int msf2_pit_si_snr_noalloc(const float* est, const float* src, float* si_snr, f
     const int nblk = cdiv(T, PIT_CHUNK);
     if ((long)B * nblk > MSF2_PIT_NOALLOC_MAX_BLOCKS) return MSF2_ERR_WORKSPACE;     // beyond the fixed array
     double* part = nullptr;
-    const int rc = scratch_for_current_device(&part);
+    int rc = scratch_for_operands(est, &part);
+    if (rc != MSF2_OK) return rc;
+    double* part_src = nullptr;
+    rc = scratch_for_operands(src, &part_src);     // both operands on the device whose array is used
     if (rc != MSF2_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     // every slot the finalize kernel reads ([B][nblk][12]) is written by the moments kernel of the same call, so

@@ -69,12 +69,15 @@ def decode_one_audio_mossformer2_ss(model, device, inputs, args, max_windows_per
     for i in range(0, len(starts), max_windows_per_call):
         o = model(wins[i:i + max_windows_per_call])
         outs.append(torch.stack(o, 0))                             # [spk, n, window]
-    o = torch.cat(outs, 1).to(torch.float64)
-    res = torch.zeros((num_spks, tp), dtype=torch.float64, device=o.device)
-    for n, s in enumerate(starts):
-        if n == 0:
-            res[:, :window - give] = o[:, 0, :window - give]
-        else:
-            res[:, s + give:s + window - give] = o[:, n, give:window - give]
+    o = torch.cat(outs, 1).to(torch.float64)                      # [spk, windows, window]
+    # Stitching as ONE gather: output sample t comes from window n(t) at offset t - n(t) * stride, where window 0 owns
+    # [0, window - give) and window n > 0 owns [n * stride + give, n * stride + window - give); samples past the last
+    # window's share stay zero (reference: utils/decode.py:56-71).
+    t = torch.arange(tp, device=o.device)
+    n = torch.clamp((t - give) // stride, min=0, max=len(starts) - 1)
+    off = t - n * stride
+    covered = off < window - give
+    flat = n * window + torch.where(covered, off, torch.zeros_like(off))
+    res = o.reshape(num_spks, -1).index_select(1, flat) * covered.to(torch.float64)
     peak = res.abs().max()
     return [a for a in (res / peak).cpu().numpy()]

@@ -172,19 +172,24 @@ class MossFormerHIP(nn.Module):
         lib, dev = self._lib, pk.device
         with self._graph_lock, torch.cuda.device(dev):
             ent = self._graphs.get((B, T))
+            if ent is not None and ent[5] is not pk:
+                ent = None                      # captured against packed weights that have been replaced since
             if ent is None:
                 nbytes = lib.msf2_workspace_bytes(pk.c_cfg, B, T)
                 if nbytes == 0:
                     raise _lib.Msf2Error("msf2_workspace_bytes rejected the configuration")
+                self._graphs.pop((B, T), None)
                 if len(self._graphs) >= self.MAX_GRAPHS:
                     self._graphs.pop(next(iter(self._graphs)))
-                xin = torch.zeros((B, T), device=dev, dtype=torch.float32)
-                out = torch.empty((self.num_spks, B, T), device=dev, dtype=torch.float32)
-                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
                 graph = torch.cuda.CUDAGraph()
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
+                    # the graph's buffers belong to the stream every replay runs on (allocated under it, so the
+                    # caching allocator orders their reuse after that stream's work when an entry is evicted)
+                    xin = torch.zeros((B, T), device=dev, dtype=torch.float32)
+                    out = torch.empty((self.num_spks, B, T), device=dev, dtype=torch.float32)
+                    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
                     # one eager pass first: a launch failure surfaces here, not inside the capture
                     _lib.check(lib.msf2_forward(pk.c_cfg, pk.struct, xin.data_ptr(), out.data_ptr(), B, T,
                                                 ws.data_ptr(), nbytes, None, side.cuda_stream), "msf2_forward")
@@ -194,9 +199,9 @@ class MossFormerHIP(nn.Module):
                                               ws.data_ptr(), nbytes, None, torch.cuda.current_stream(dev).cuda_stream)
                     _lib.check(rc, "msf2_forward (graph capture)")
                 torch.cuda.current_stream(dev).wait_stream(side)
-                ent = (graph, xin, out, ws, side)
+                ent = (graph, xin, out, ws, side, pk)       # pk: the graph holds pointers into these packed weights
                 self._graphs[(B, T)] = ent
-            graph, xin, out, _, side = ent
+            graph, xin, out, _, side, _ = ent
             # The graph is always launched on the stream it was captured on, ordered against the caller's stream by
             # events on both sides (launched on the null stream, replays were not ordered against the copies around
             # them on ROCm 7.2).  Replays of one shape therefore run one after the other.

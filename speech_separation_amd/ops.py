@@ -137,11 +137,22 @@ def pit_si_snr(est, src):
 
 def pit_si_snr_noalloc(est, src, si, best, perm):
     """pit_si_snr for callers that cannot allocate: every buffer, outputs included, comes from the caller and the
-    library's partial sums live in its fixed device array (msf2_pit_si_snr_noalloc).  Nothing is allocated here."""
+    library's partial sums live in its fixed device array (msf2_pit_si_snr_noalloc).  Nothing is allocated here.
+    The library uses the array of the thread's current device, so the call is made with the operands' device current."""
     lib = _lib.load()
+    _chk(est, src, si, best)
+    if est.shape != src.shape or est.dim() != 3 or est.shape[0] != 2:
+        raise ValueError("est and src must both be [2, B, T]")
     _, B, T = est.shape
-    _lib.check(lib.msf2_pit_si_snr_noalloc(est.data_ptr(), src.data_ptr(), si.data_ptr(), best.data_ptr(), perm.data_ptr(),
-                                           B, T, _stream(est)), "msf2_pit_si_snr_noalloc")
+    if not (perm.is_cuda and perm.dtype == torch.int32 and perm.is_contiguous() and tuple(perm.shape) == (B,)):
+        raise ValueError("perm must be a contiguous int32 tensor [B] on the GPU")
+    if tuple(si.shape) != (B, 2, 2) or tuple(best.shape) != (B,):
+        raise ValueError("si must be [B, 2, 2] and best [B]")
+    if any(t.device != est.device for t in (src, si, best, perm)):
+        raise ValueError("all tensors must live on one GPU")
+    with torch.cuda.device(est.device):
+        _lib.check(lib.msf2_pit_si_snr_noalloc(est.data_ptr(), src.data_ptr(), si.data_ptr(), best.data_ptr(), perm.data_ptr(),
+                                               B, T, _stream(est)), "msf2_pit_si_snr_noalloc")
 
 
 def gated_fsmn(x, packed):

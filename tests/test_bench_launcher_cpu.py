@@ -10,13 +10,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(extra_env=None, gpus=2, steps=3, warmup=1):
+def _run(extra_env=None, gpus=2, steps=3, warmup=1, workload="c2", extra=()):
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
     return subprocess.run([sys.executable, BENCH, "--gpus", str(gpus), "--steps", str(steps), "--warmup", str(warmup),
-                           "--batch", "2", "--seconds", "0.5", "--stub-cpu"],
+                           "--batch", "2", "--seconds", "0.5", "--stub-cpu"]
+                          + (["--workload", workload] if workload else []) + list(extra),
                           env=env, capture_output=True, text=True, timeout=300)
+
+
+def _line(r):
+    # (gloo itself prints a "[Gloo] Rank 0 is connected ..." notice on stdout; RCCL does not)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_sweep_is_the_default_on_several_ranks_and_scales_strongly():
+    """Without --workload, N > 1 runs the utterance sweep: one plan over all ranks, a step = 1/steps of each rank's
+    share, SI-SDR sums reduced and every output gathered inside the timed region."""
+    r = _run(workload=None, steps=4, warmup=2, extra=("--utterances", "90"))
+    assert r.returncode == 0, r.stderr
+    rec = _line(r)
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and rec["scaling"] == "strong"
+    assert rec["steps"] == 4 and rec["warmup"] == 2
+    assert rec["config"]["utterances"] == 90 and rec["utterances_in_statistic"] == 90.0
+    assert len(rec["busy_s_per_rank"]) == 2 and len(rec["items_per_rank"]) == 2 and sum(rec["items_per_rank"]) > 0
+    assert 1.0 <= rec["lpt_imbalance"] < 1.1
+    assert rec["ms_per_step"] == max(rec["ms_per_step_per_rank"])
+    assert rec["outputs_finite"] and rec["spot_check_rel_err_vs_alone"] == 0.0
+    # warm-up exchange (reduce + gather), two fences, the timed exchange (reduce + gather), the gather of rank times
+    assert rec["collectives_per_rank"] == 2 + 2 + 2 + 1
+    assert rec["value"] > 0
+
+
+def test_sweep_on_one_rank_needs_no_collective():
+    r = _run(gpus=1, workload="c5", extra=("--utterances", "40"))
+    assert r.returncode == 0, r.stderr
+    rec = _line(r)
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "strong" and rec["collectives_per_rank"] == 0
+    assert rec["lpt_imbalance"] == 1.0 and rec["utterances_in_statistic"] == 40.0
 
 
 def test_plain_invocation_spawns_ranks_and_prints_one_line():

@@ -14,8 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_collectives_of_the_multi_rank_path_on_rccl():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
                         "--seconds", "1", "--collectives-at-one-rank", "--no-secondary", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
@@ -57,7 +64,7 @@ print(json.dumps({"ok": bool(ok), "n": len(gathered), "count": st1[2]}))
 def test_sharded_sweep_reduction_and_gather_on_rccl():
     """The utterance-sharded sweep (config 5's path): its SI-SDR reduction and its output gather over RCCL with one rank
     give what the collective-free single-process path gives."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port())
     p = subprocess.run([sys.executable, "-c", SHARDED % ROOT], env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])

@@ -278,6 +278,9 @@ def test_full_model_matches_reference(models, golden_dir):
     assert err <= 1e-3                      # the stated contract, raw outputs
     assert err <= 1e-3 * peak               # and on the peak-normalised scale
     assert err64 <= 1e-3 * peak
+    # what the kernels actually deliver (measured 1.2e-7 absolute = 9e-7 of the peak): a regression of one order of
+    # magnitude fails here long before it reaches the contract
+    assert err <= 5e-6 * peak
 
 
 @pytest.mark.parametrize("B,T", [(1, 16), (2, 24), (1, 700), (3, 1031), (1, 2055)])
@@ -376,7 +379,7 @@ def test_bf16_full_model_si_sdr(golden_dir):
     print(f"bf16 full model: SI-SDR delta {d:+.4f} dB; fidelity to fp32 reference {fid[0]:.1f} / {fid[1]:.1f} dB; "
           f"max-abs {np.abs(got - ref).max():.3e} (peak {np.abs(ref).max():.3e})")
     assert abs(d) <= 0.05
-    assert min(fid) >= 30.0
+    assert min(fid) >= 38.0                 # measured 42-43 dB
 
 
 @pytest.mark.parametrize("name,B,T", [("tiny", 2, 8003), ("tiny", 3, 6408), ("small", 1, 16000), ("full", 3, 20000)])
@@ -520,7 +523,9 @@ def test_long_form_matches_reference(models, golden_dir, name):
     got = out.cpu().numpy()[:, :, ::stride]
     err = np.abs(got - ref).max()
     print(f"long form {name}: fp32 max-abs err {err:.3e} (peak {float(z['out_peak']):.3e})")
-    assert err <= (1e-3 * float(z["out_peak"]) if name == "full" else 1e-5)
+    # measured 4.1e-8 / 3.9e-8 (tiny, small) and 1.4e-7 (24 layers, peak ~ 0.1)
+    assert err <= (1e-5 * float(z["out_peak"]) if name == "full" else 1e-6)
+    assert err <= 1e-3                      # the stated contract
     m16 = MossFormerHIP(CFG[name], compute_device=DEV, precision=BF)
     m16.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(CFG[name], 0).items()})
     got16 = torch.stack(m16(x), 0).cpu().numpy()[:, :, ::stride]
@@ -831,7 +836,7 @@ def test_bf16_mode_on_reference_fixtures(golden_dir, name):
             for b in range(got.shape[1]):
                 worst = min(worst, si_sdr(got[s, b], z["out"][s, b]))
     print(f"bf16 mode, {name} fixtures: worst fidelity {worst:.1f} dB")
-    assert worst >= 30.0
+    assert worst >= 40.0                    # measured 45.3 - 46.9 dB
 
 
 def test_gated_fsmn_block(golden_dir):

@@ -52,3 +52,24 @@ def test_noalloc_entry_point_matches_workspace_entry_point():
     torch.cuda.synchronize()
     assert rc == -2 and bool((si == 7.0).all())
     assert lib.msf2_pit_si_snr_noalloc(None, None, None, None, None, 1, 100, None) == -1
+
+
+def test_noalloc_entry_point_refuses_operands_off_the_current_device():
+    """The fixed array used is the one of the thread's current device: waveforms that do not live in that device's
+    memory (here: plain host memory) are refused before anything is launched, and the wrapper checks shapes and types
+    of the caller's output buffers (a short or mistyped `perm` would be written out of bounds)."""
+    lib = _lib.load()
+    host = np.zeros((2, 1, 4096), dtype=np.float32)
+    best = torch.full((1,), 5.0, device=DEV)
+    rc = lib.msf2_pit_si_snr_noalloc(host.ctypes.data, host.ctypes.data, None, best.data_ptr(), None, 1, 4096, None)
+    torch.cuda.synchronize()
+    assert rc == -1 and float(best[0]) == 5.0
+    est, src = _case(2, 5000, 3)
+    si = torch.empty((2, 2, 2), device=DEV)
+    with pytest.raises(ValueError):
+        ops.pit_si_snr_noalloc(est, src, si, torch.empty(2, device=DEV), torch.empty(2, dtype=torch.int64, device=DEV))
+    with pytest.raises(ValueError):
+        ops.pit_si_snr_noalloc(est, src, si, torch.empty(2, device=DEV), torch.empty(1, dtype=torch.int32, device=DEV))
+    with pytest.raises(ValueError):
+        ops.pit_si_snr_noalloc(est, src[:, :1].contiguous(), si, torch.empty(2, device=DEV),
+                               torch.empty(2, dtype=torch.int32, device=DEV))
