@@ -10,6 +10,7 @@
 #include "msf2_common.h"
 #include "msf2_gemm.h"
 #include "msf2_gemm_bf16.h"
+#include "msf2_gemm_bf16_astat.h"
 #include "msf2_attn_fused.h"
 #include "msf2_ops.h"
 
@@ -84,6 +85,8 @@ struct Knobs {
     int row128 = 1;             // "row128": 1 = the two-product contraction on whole-line row pieces, one column tile per workgroup; 2 = every
                                 //           projection that reaches the 128 x 128 stream form; 0 = none
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
+    bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
+    bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -134,6 +137,7 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
     // bf16 mode with a bf16 image of the A operand(s): both operands stream global -> LDS
     // the epilogue moves 4 consecutive columns per lane as one vector
     auto al = [](const void* p, unsigned mask) { return (reinterpret_cast<uintptr_t>(p) & mask) == 0; };
+    auto al16 = [&](const void* p) { return al(p, 15); };
     if ((a.N & 3) || (a.ldo & 3) || (a.ldr & 3) || !al(a.out, 15) || !al(a.out2, 15) || !al(a.res, 15) || !al(a.pe, 15) ||
         !al(a.gmul, 15) || !al(a.bias, 15) || !al(a.bias2, 15) || !al(a.c1, 15) || !al(a.c2, 15) || !al(a.out16, 7) ||
         !al(a.res16, 7)) {
@@ -151,6 +155,20 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         // 4 tiles re-reads A from the fabric 4 times (FETCH_SIZE 2.4 GB instead of 0.9 GB per launch).
         int loop = c.k.ncol_loop;
         ProjArgs al = a;
+        al.store_aware = c.k.store_aware ? 1 : 0;
+        if constexpr (EPI == EPI_RS_BIAS_ACT) {
+            // Activation rows resident in registers, weights streamed: one 4-wave workgroup per 128 rows walks every column
+            // tile.  Needs a workgroup per CU at least (fewer: the tile forms below spread over the chip better), a bf16-only
+            // output and K = 512 (a wave holds 64 rows x 512 k as 256 registers).
+            const long wgs = (long)cdiv(c.S, 128) * c.B;
+            if (c.k.astat && a.K == 512 && a.N % 128 == 0 && a.N <= 4096 && a.out16 && !a.out && !a.out2 && (a.act == 1 || a.act == 2) &&
+                (a.lda & 7) == 0 && (a.ldo & 7) == 0 && al16(a.A16) && al16(a.out16) && al16(a.W) && wgs >= c.cus) {
+                const dim3 g(cdiv(c.S, 128), c.B);
+                if (a.act == 1) hipLaunchKernelGGL((proj_astat_bf16_kernel<AMODE, 1>), g, dim3(256), 0, c.st, al);
+                else hipLaunchKernelGGL((proj_astat_bf16_kernel<AMODE, 2>), g, dim3(256), 0, c.st, al);
+                return 0;
+            }
+        }
         if constexpr (!P::PAIRED && AMODE == A_PLAIN) {
             // fewer 128-row tiles than CUs (one utterance per call): 64-row tiles, twice the workgroups
             if (small_grid(c, a.N)) {
@@ -759,6 +777,8 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
+    else if (!strcmp(name, "store_aware")) k.store_aware = atoi(value) != 0;
+    else if (!strcmp(name, "astat")) k.astat = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused")) k.attn_fused = atoi(value) != 0;
     else if (!strcmp(name, "attn_fused_min")) k.attn_fused_min = atoi(value);
     else if (!strcmp(name, "geom3")) { strncpy(k.g3, value, sizeof(k.g3) - 1); k.g3[sizeof(k.g3) - 1] = 0; }

@@ -357,6 +357,7 @@ struct ProjArgs {
     const unsigned short* res16;   // residual read as bf16 instead of res (same pitch ldr)
     float* sq_part;                // EPI_NORM / EPI_BIAS_RES, row-major epilogue: optional [M][ceil(N / w)] sums of out^2 over the w columns of a wave's slab
     int ncol_loop;                 // DMA kernel: consecutive column tiles one workgroup walks (0 = 1); grid.x shrinks accordingly
+    int store_aware;               // DMA kernel walking several tiles: waits behind an epilogue leave its output stores outstanding
     // EPI_TCN / EPI_TCN_G, small-grid tile forms only (init_tile): the utterance statistics as stage A left them, [B][stat_nblk][2]
     // partial (sum, sum of squares); the kernel reduces them itself (bstat and c1f null) in the order stats_finalize_kernel does.
     const float* stat_part;  int stat_nblk;  float stat_eps;  double stat_count;

@@ -433,8 +433,24 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
     };
     // Tile `idx` has landed once at most the copies of the tiles issued after it are outstanding.  Loads,
     // stores and copies retire in issue order, so epilogue stores issued in between only make this stricter.
+    // Output stores count on the same counter.  A wave whose 64 x 64 (TM x TN tiles) region lies wholly inside the
+    // output issues exactly EPI_STORES of them per epilogue (one 8-byte store per row group and MFMA tile, no lane
+    // masked off, so no store instruction is branched around); tiles issued BEFORE those stores (stream index below
+    // `mark`) may then be awaited with that many more operations outstanding, which lets the stores drain under the
+    // K steps that follow instead of in front of them.  Any other wave keeps the strict counts (mark_stores == 0).
+    constexpr int EPI_STORES = 4 * TM * (P::PAIRED ? TN / 2 : TN);
+    constexpr bool STORE_AWARE = MULTI && !P::PAIRED && EPI_STORES + 3 * DMA_PER_TILE <= 63;
+    int mark = 0;
+    bool mark_stores = false;
     auto wait_tile = [&](int idx) __attribute__((always_inline)) {
         const int after = issued - idx - 1;
+        if (STORE_AWARE && mark_stores && idx < mark) {
+            if (after <= 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(EPI_STORES) : "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE + EPI_STORES) : "memory");
+            else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE + EPI_STORES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMA_PER_TILE + EPI_STORES) : "memory");
+            return;
+        }
         if (after <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
         else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
@@ -523,6 +539,11 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
         // being refilled exactly NST - 2 younger tiles are behind it (three right after a column tile's residual tiles: then
         // this is one tile stricter than needed); once nothing is left to issue, everything is awaited.
         if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (STORE_AWARE && mark_stores && cons < mark) {
+            // tile `cons` went out before the last epilogue's stores: they may still be outstanding behind it
+            if (issued < total) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((NST - 2) * DMA_PER_TILE + EPI_STORES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(EPI_STORES) : "memory");
+        }
         else if (__builtin_expect(issued < total, 1)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((NST - 2) * DMA_PER_TILE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         MSF2_STAMP(q1)
@@ -591,12 +612,24 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
         // when it ends: by then they have long arrived, and nothing waits on them behind the copies in flight.
         CV cvn;
         const bool more = MULTI && rep + 1 < nrep;
+        // (called right after the epilogue, before anything else is issued: `mark` separates the tiles that went out
+        // before its stores from those that follow them)
+        auto set_mark = [&]() __attribute__((always_inline)) {
+            if constexpr (STORE_AWARE) {
+                // exactly one store per row group and MFMA tile, by every lane: the wave's region is interior and the epilogue
+                // writes one output (anything else -- an edge tile, a second output -- keeps the strict waits)
+                const int per_group = (prob.a.out ? 1 : 0) + (prob.a.out16 ? 1 : 0) + (prob.a.out2 ? 1 : 0);
+                mark = issued;
+                mark_stores = prob.a.store_aware && per_group == 1 && prob.s0 + (wr + 1) * (TM * 32) <= prob.a.S && prob.n0 + (wc + 1) * (TN * 32) <= prob.a.N;
+            }
+        };
         auto next_vecs = [&]() __attribute__((always_inline)) { if (more) prob.template load_colvecs<TN, FOLDED>(prob.n0 + G::NWX, wc, lane, cvn); };
         if constexpr (RESLDS) {
             // the residual tile(s) are stream tiles cons .. cons + NRES - 1, RROWS rows of 256 B each
             wait_tile(cons + NRES - 1);
             __builtin_amdgcn_s_barrier();
             prob.template epilogue_rm<TM, TN, true>(acc, wr, wc, lane, stage, cv, sm + slot(cons + (wr * TM * 32) / RROWS) * STAGE + ((wr * TM * 32) % RROWS) * 256, next_vecs);
+            set_mark();
             cons += NRES;
 #ifdef MSF2_DIAG_DRAIN_AFTER_EPI
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing-only build: every store acknowledged before the stream goes on
@@ -607,6 +640,7 @@ __global__ __launch_bounds__((DmaGeom<P, BIG>::THREADS), (DmaGeom<P, BIG>::MINB)
                 if (issued < total) issue();
         } else {
             prob.template epilogue_rm<TM, TN, false>(acc, wr, wc, lane, stage, cv, nullptr, next_vecs);
+            set_mark();
         }
         if (more) {
             prob.template fold_colvecs<TN, FOLDED>(cvn);

@@ -457,6 +457,30 @@ def test_bf16_kernel_choices_agree():
         assert torch.equal(outs_p[name], outs_p["default"]), name + " (projection)"
 
 
+@pytest.mark.parametrize("B,T", [(8, 32000), (11, 20011)])
+def test_bf16_register_resident_projection_agrees(B, T):
+    """The bf16 K = 512 projections with a bias / activation epilogue (token-shifted to_hidden | to_qk, N = 2176, and the
+    gate of the gated TCN block) run on the kernel that keeps the activation rows in registers and streams only the
+    weights once a call has a workgroup per CU.  Same arithmetic in the same order per output element as the tile
+    kernels it replaces: the forward must not depend on which one ran (2 layers at the real widths; the second length
+    leaves a partial row tile of 3 rows)."""
+    cfg2 = type(FULL_8K)(num_layers=2)
+    m = MossFormerHIP(cfg2, compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg2, 0).items()})
+    x = torch.from_numpy(synth_batch(B, T, seed0=3)).to(DEV)
+    lib = _lib.load()
+    outs = {}
+    for val in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(None, None))
+        _lib.check(lib.msf2_debug_kernel_choice(b"astat", val))
+        try:
+            outs[val] = torch.stack(m(x), 0)
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    assert torch.isfinite(outs[b"1"]).all()
+    assert torch.equal(outs[b"1"], outs[b"0"])
+
+
 def test_bf16_batch_independence():
     """bf16 mode, full model: an utterance gives the same waveform alone and inside a batch of 12, up to
     bf16 rounding noise: the linear-attention summary is split over time in a batch-dependent number of

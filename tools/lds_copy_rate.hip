@@ -33,8 +33,16 @@ constexpr int KBYTES = 1024;  // K = 512 bf16
 
 // ROWB: bytes per row piece; NST: ring slots; a slot = 128 activation rows + 128 weight rows of ROWB bytes.
 // SRC: 1 activations only, 2 weights only, 3 both.
-template <int ROWB, int NST, int MINB, int SRC>
-__global__ __launch_bounds__(256, MINB) void copy_rate(Args a) {
+// touch: one dword of a line, copied into a 256-byte dummy area of LDS (no register destination, nothing ever waits for it)
+__device__ __forceinline__ void touch_so(const void* base, unsigned byte_off, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+                 :: "v"(byte_off), "s"(base), "s"(lds_base) : "memory", "m0");
+}
+
+// PF > 0: a fifth wave per workgroup touches the activation lines of the k tile PF tiles ahead of the consumer (its quarter
+// of the 128 rows when `share` workgroups read the same row tile), so that the copies find them in the XCD's L2.
+template <int ROWB, int NST, int MINB, int SRC, int PF = 0>
+__global__ __launch_bounds__((PF > 0 ? 320 : 256), MINB) void copy_rate(Args a) {
     constexpr int TILE = 128 * ROWB, STAGE = 2 * TILE;
     constexpr int RPI = 1024 / ROWB, LPR = ROWB / 16;         // rows per wave instruction, lanes per row
     constexpr int PA = 128 / RPI / 4;                         // copies per wave, operand and k tile
@@ -55,6 +63,28 @@ __global__ __launch_bounds__(256, MINB) void copy_rate(Args a) {
         off[i] = (unsigned)(row * PITCH + (lane % LPR) * 16);
     }
     const int total = a.ncol * 2 * NKT;
+    if (PF > 0 && wave == 4) {
+        // rows of this helper: 128 / share of them, two 64-byte halves each, spread over the lanes
+        const int nshare = a.share > 1 ? a.share : 1;
+        const int rows_mine = 128 / nshare, rbase = col0 * rows_mine;
+        const unsigned dummy = __builtin_amdgcn_readfirstlane(lds_addr_of(sm + NST * STAGE));
+        auto touch_tile = [&](int idx) {
+            if (idx >= total) return;
+            const int t = idx % (2 * NKT), prod = t / NKT, kt = t % NKT;
+            const char* A = (prod ? a.t : a.h) + row0 * PITCH + kt * ROWB;
+            for (int e = lane; e < rows_mine * (ROWB / 64); e += 64) {
+                const int row = rbase + e / (ROWB / 64), half = e % (ROWB / 64);
+                touch_so(A, (unsigned)(row * PITCH + half * 64), dummy);
+            }
+        };
+        for (int i = 0; i < PF + NST - 1; ++i) touch_tile(i);
+        for (int c = 0; c < total; ++c) {
+            touch_tile(c + PF + NST - 1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
     int issued = 0;
     auto issue = [&]() __attribute__((always_inline)) {
         const int t = issued % (2 * NKT), col = issued / (2 * NKT);
@@ -98,17 +128,18 @@ __global__ __launch_bounds__(256, MINB) void copy_rate(Args a) {
     if (acc == 0x12345678u) a.sink[0] = acc;
 }
 
-template <int ROWB, int NST, int MINB, int SRC>
+template <int ROWB, int NST, int MINB, int SRC, int PF = 0>
 static void run1(const char* name, Args a, int wgs_per_cu_lds_pad) {
     const int lds = NST * 2 * 128 * ROWB + wgs_per_cu_lds_pad;
-    CK(hipFuncSetAttribute((const void*)copy_rate<ROWB, NST, MINB, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int threads = PF > 0 ? 320 : 256;
+    CK(hipFuncSetAttribute((const void*)copy_rate<ROWB, NST, MINB, SRC, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int grid = a.M / 128 * a.share;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_rate<ROWB, NST, MINB, SRC>), dim3(grid), dim3(256), lds, 0, a);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((copy_rate<ROWB, NST, MINB, SRC, PF>), dim3(grid), dim3(threads), lds, 0, a);
     CK(hipEventRecord(e0));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_rate<ROWB, NST, MINB, SRC>), dim3(grid), dim3(256), lds, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((copy_rate<ROWB, NST, MINB, SRC, PF>), dim3(grid), dim3(threads), lds, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -128,6 +159,12 @@ static void run_shared(Args a) {
     printf("-- source: %s, one column tile per workgroup, 4 workgroups per row tile, pitch %d\n", SRC == 3 ? "activations + weights" : SRC == 1 ? "activations only" : "weights only", a.pitch);
     run1<64, 4, 2, SRC>("64 B pieces, 4 slots x 16 KB, 2 wg/CU", a, 16384);
     run1<128, 2, 2, SRC>("128 B pieces, 2 slots x 32 KB, 2 wg/CU", a, 16384);
+    if (SRC & 1) {
+        run1<128, 2, 2, SRC, 1>("  + helper wave touching lines 1 tile ahead", a, 16384);
+        run1<128, 2, 2, SRC, 2>("  + helper wave touching lines 2 tiles ahead", a, 16384);
+        run1<128, 2, 2, SRC, 4>("  + helper wave touching lines 4 tiles ahead", a, 16384);
+        run1<128, 2, 2, SRC, 8>("  + helper wave touching lines 8 tiles ahead", a, 16384);
+    }
     run1<128, 4, 1, SRC>("128 B pieces, 4 slots x 32 KB, 1 wg/CU", a, 16384);
     run1<64, 2, 4, SRC>("64 B pieces, 2 slots x 16 KB, 4 wg/CU", a, 0);
 }
@@ -159,7 +196,7 @@ int main(int argc, char** argv) {
     a.h = h; a.t = t; a.w = w; a.M = M; a.sink = sink; a.pitch = 1024;
     printf("rows %d (batch %d x 3999 frames), %d row tiles\n", M, B, M / 128);
     if (argc > 2) {         // the shared-row pattern at several row pitches
-        for (int pitch : {1024, 1152}) {
+        for (int pitch : {1024}) {
             a.pitch = pitch;
             run_shared<3>(a);
             run_shared<1>(a);
