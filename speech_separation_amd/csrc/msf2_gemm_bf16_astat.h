@@ -33,12 +33,25 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // (all 256 of them; an MFMA reads its A / B operands from either file).  c += w x a, or c = w x a for the first step.
 // Nothing else ever writes these registers between MFMAs, consecutive MFMAs go to different accumulator tiles, and the
 // first VALU read of a finished tile comes a whole k tile after its last MFMA, so no wait states are needed here.
-__device__ __forceinline__ void mfma_astat(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
+#ifdef MSF2_DIAG_ASTAT_ACC_AGPR
+// experiment: accumulators in the accumulator file, the activation fragments of the first 32 rows there too and those of
+// the second 32 rows in VGPRs
+template <int TM> __device__ __forceinline__ void mfma_astat(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
+    if constexpr (TM == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "a"(act));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(act));
+}
+template <int TM> __device__ __forceinline__ void mfma_astat_first(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
+    if constexpr (TM == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "a"(act));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(act));
+}
+#else
+template <int TM> __device__ __forceinline__ void mfma_astat(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "a"(act));
 }
-__device__ __forceinline__ void mfma_astat_first(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
+template <int TM> __device__ __forceinline__ void mfma_astat_first(f32x16& c, const u32x4_t& w, const u32x4_t& act) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(w), "a"(act));
 }
+#endif
 
 template <int AMODE, int ACT>
 __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs a) {
@@ -95,21 +108,34 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     }
     const unsigned short* wnext = reinterpret_cast<const unsigned short*>(a.W);     // source of the next stage: column tile, k tile
     const unsigned ring = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
+    auto copy_piece = [&](int slot, int i) __attribute__((always_inline)) {
+        dma16_so(wnext, off[i], ring + slot * STAGE + (wave * D + i) * 1024);
+    };
     auto copy_stage = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            dma16_so(wnext, off[i], ring + slot * STAGE + (wave * D + i) * 1024);
+        for (int i = 0; i < D; ++i) copy_piece(slot, i);
     };
     const long tile_step = (long)128 * K - (KT - 1) * 64;   // from the last k tile of a column tile to the first of the next
 #pragma unroll
-    for (int t = 0; t < NST; ++t) {                        // stages 0 .. 3 = k tiles 0 .. 3 of column tile 0
+    for (int t = 0; t < NST - 1; ++t) {                    // stages 0 .. 2 = k tiles 0 .. 2 of column tile 0, and piece 0 of stage 3
         copy_stage(t);
         wnext += 64;
     }
+    copy_piece(NST - 1, 0);
 
     const int rowB = wc * 64 + l31;
     const char* fbase = sm + rowB * 128;
+    auto read_b1 = [&](int slot, int sub, int tn, u32x4_t& dst) __attribute__((always_inline)) {
+#ifdef MSF2_DIAG_ASTAT_NOREAD
+        if (slot >= 0) return;         // timing-only build: no fragment reads
+#endif
+        const int row = rowB + tn * 32;
+        dst = *reinterpret_cast<const u32x4_t*>(fbase + slot * STAGE + tn * 32 * 128 + (((2 * sub + kh) ^ bf_swz128(row)) << 4));
+    };
     auto read_b = [&](int slot, int sub, u32x4_t (&fb)[2]) __attribute__((always_inline)) {
+#ifdef MSF2_DIAG_ASTAT_NOREAD
+        if (slot >= 0) return;         // timing-only build: no fragment reads
+#endif
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int row = rowB + tn * 32;
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     bool st_ok[2] = {false, false};     // whether this lane stores its row of a finished tile (false while there is none)
     u32x2_t pk[4];
     float4 bq[2][2];               // bias of the two accumulator groups finished per k tile: [k tile parity][group]
-    float xv = 0.f, ex = 0.f, val[4] = {0.f, 0.f, 0.f, 0.f};
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
 
     // bias of groups g0, g0 + 1 of MFMA tile q of the column tile starting at nb (broadcast reads: two addresses per wave)
     auto load_bias = [&](float4 (&dst)[2], int q, int g0, int nb) __attribute__((always_inline)) {
@@ -129,33 +155,66 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         dst[0] = *reinterpret_cast<const float4*>(p + 8 * g0);
         dst[1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
     };
-    // One half of the arithmetic of one output value, small enough to issue in the shadow of one MFMA (each half holds
-    // one quarter-rate instruction).  Slot m = 0 .. 15 of k tile kt finishes element (m >> 1) & 3 of accumulator group
-    // 2 (kt & 1) + (m >> 3) of MFMA tile kt >> 1 of the PREVIOUS column tile (accumulator set PAR ^ 1).
+    // The arithmetic of one accumulator group (4 values of one row) takes the shadows of 8 MFMAs, one phase per MFMA, each
+    // phase a handful of mutually INDEPENDENT instructions (a wave alone on its SIMD issues in order: an instruction that
+    // needs the result of the one before it stalls the wave, and with it the next MFMA; the phases of a group depend on each
+    // other only across MFMAs).  Slot m = 0 .. 15 of k tile kt is phase m & 7 of accumulator group 2 (kt & 1) + (m >> 3) of
+    // MFMA tile kt >> 1 of the PREVIOUS column tile (accumulator set PAR ^ 1).  exp(-x) is written as the multiply and
+    // v_exp_f32 that __expf(-x) compiles to, so that the two can sit in different phases.
+    // The empty statements pin each phase between the MFMA issued before it and the one after it: they are ordered against
+    // the MFMA statements, and the arithmetic hangs on their operands (the optimiser otherwise gathers all of a k tile's
+    // arithmetic behind its last MFMA, where nothing hides it).
+    float ex[4] = {0.f, 0.f, 0.f, 0.f};
     auto epi_slot = [&](auto par_tag, int kt, int m) __attribute__((always_inline)) {
         constexpr int PP = decltype(par_tag)::value ^ 1;
+        constexpr bool SIG = (ACT == 1 || ACT == 2);
         const int q = kt >> 1, tm = q >> 1, tn = q & 1;
-        const int gi = m >> 3, g = (kt & 1) * 2 + gi, e = (m >> 1) & 3;
-        // The empty statements pin each half between the MFMA issued before it and the one after it: they are ordered
-        // against the MFMA statements, and the arithmetic hangs on their operands (the optimiser otherwise gathers all
-        // of a k tile's arithmetic behind its last MFMA, where nothing hides it).
-        if ((m & 1) == 0) {
-            float r = r0[tm];
-            asm volatile("" : "+v"(r));
-            xv = r * acc[PP][tm][tn][4 * g + e] + f4get(bq[kt & 1][gi], e);
-            if constexpr (ACT == 1 || ACT == 2) ex = __expf(-xv);
-            asm volatile("" : "+v"(xv), "+v"(ex));
-        } else {
-            asm volatile("" : "+v"(ex));
-            if constexpr (ACT == 1) val[e] = xv * __builtin_amdgcn_rcpf(1.0f + ex);
-            else if constexpr (ACT == 2) val[e] = __builtin_amdgcn_rcpf(1.0f + ex);
-            else val[e] = xv;
-            asm volatile("" : "+v"(val[e]));
-            if (e == 3) {
-                pk[g].x = pk_bf16_2(val[0], val[1]);
-                pk[g].y = pk_bf16_2(val[2], val[3]);
-                asm volatile("" : "+v"(pk[g].x), "+v"(pk[g].y));
+        const int gi = m >> 3, g = (kt & 1) * 2 + gi, ph = m & 7;
+        if (ph == 0) {
+            asm volatile("" : "+v"(r0[tm]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = r0[tm] * acc[PP][tm][tn][4 * g + e] + f4get(bq[kt & 1][gi], e);
+            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+        } else if (ph == 1) {
+            if constexpr (SIG) {
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ex[e] = val[e] * -1.44269504f;          // -log2(e)
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
             }
+        } else if (ph == 2 || ph == 3) {
+            if constexpr (SIG) {
+                const int e0 = (ph - 2) * 2;
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+                ex[e0] = __builtin_amdgcn_exp2f(ex[e0]);
+                ex[e0 + 1] = __builtin_amdgcn_exp2f(ex[e0 + 1]);
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+            }
+        } else if (ph == 4) {
+            if constexpr (SIG) {
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ex[e] = 1.0f + ex[e];
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+            }
+        } else if (ph == 5 || ph == 6) {
+            if constexpr (SIG) {
+                const int e0 = (ph - 5) * 2;
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+                ex[e0] = __builtin_amdgcn_rcpf(ex[e0]);
+                ex[e0 + 1] = __builtin_amdgcn_rcpf(ex[e0 + 1]);
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+            }
+        } else {
+            asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (ACT == 1) val[e] = val[e] * ex[e];
+                else if constexpr (ACT == 2) val[e] = ex[e];
+            }
+            pk[g].x = pk_bf16_2(val[0], val[1]);
+            pk[g].y = pk_bf16_2(val[2], val[3]);
+            asm volatile("" : "+v"(pk[g].x), "+v"(pk[g].y));
         }
     };
     // the four packed groups of MFMA tile q -> two 16-byte stores per lane (rows of 64 contiguous bytes per tile)
@@ -176,51 +235,78 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     // per two k tiles.  The first column tile runs the same code on a zeroed set with its stores masked off, and the
     // weight stream wraps around to column tile 0 after the last one (four stages that nobody reads), so every column
     // tile is the same straight-line code and the stream never has to be wound down inside the loop.
-    // Order of the counted operations per k tile kt: [wait for stage kt + 1] [4 copies] ... [2 stores if kt is odd].
+    // The four copies of a stage are spread over four MFMA steps (issuing one holds the wave for tens of cycles: back to
+    // back they would leave the matrix pipe idle for most of that): piece 0 right after the barrier that releases the
+    // slot, pieces 1 - 3 in the first three MFMA steps of the next k tile.
+    // Order of the counted operations per k tile kt: [pieces 1 2 3 of stage kt + 3] [wait for stage kt + 1] [piece 0 of
+    // stage kt + 4] [2 stores if kt is odd]: two stages and one pair of stores are younger than the awaited stage.
     u32x4_t fb[2][2];              // weight fragments of two consecutive MFMA steps (ping-pong: step parity)
     auto column_tile = [&](auto par_tag, int ct, bool counted) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const int nprev = (ct - 1) * 128;
-        const bool wrap = ct == NT - 1;
+        // (the source pointer moves on after piece 3 of a stage; the stage in flight when k tile 4 starts is the last k tile
+        // of this column tile, so the pointer then steps to the next column tile -- or wraps)
+        const bool wrap_prev = ct == NT - 1;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                if (sub < 3) {
-                    read_b(kt & 3, sub + 1, fb[(sub + 1) & 1]);
-                } else {
-                    // the fragments of MFMA step 3 are in registers and the next stage has landed; then every wave is
-                    // done reading this stage and it can be refilled
+                // One memory instruction per MFMA shadow at most (issuing one holds the wave for 16 - 60 cycles, and the
+                // matrix pipe runs dry behind a wave that is held for longer than one MFMA lasts): after MFMA 0 and 1
+                // the two fragment reads of the next MFMA step, after MFMA 2 one piece of the weight stream.
+                if (sub == 3) {
+                    // the fragments of this step are in registers and the next stage has landed; then every wave is done
+                    // reading this stage and it can be refilled
                     if (counted) {
-                        if (kt & 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D + 2) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D + 4) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D + 2) : "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D) : "memory");
                     }
+#ifndef MSF2_DIAG_ASTAT_NOBARRIER
                     __builtin_amdgcn_s_barrier();
-                    read_b((kt + 1) & 3, 0, fb[0]);
-                    copy_stage(kt & 3);                             // stream tile + 4 goes into the slot just released
-                    if (kt == KT - NST - 1) wnext = wrap ? reinterpret_cast<const unsigned short*>(a.W) : wnext + tile_step;
-                    else wnext += 64;
-                    // bias of the two groups the NEXT k tile finishes (the next column tile's first, after the last k tile)
-                    if (kt < KT - 1) load_bias(bq[(kt + 1) & 1], (kt + 1) >> 1, ((kt + 1) & 1) * 2, nprev);
-                    else load_bias(bq[0], 0, 0, nprev + 128);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (kt == 0 && sub == 0) mfma_astat_first(acc[PAR][j >> 1][j & 1], fb[0][j & 1], afr[j >> 1][0]);
-                    else mfma_astat(acc[PAR][j >> 1][j & 1], fb[sub & 1][j & 1], afr[j >> 1][kt * 4 + sub]);
+                    if (kt == 0 && sub == 0) {
+                        if (j < 2) mfma_astat_first<0>(acc[PAR][0][j & 1], fb[0][j & 1], afr[0][0]);
+                        else mfma_astat_first<1>(acc[PAR][1][j & 1], fb[0][j & 1], afr[1][0]);
+                    } else {
+                        if (j < 2) mfma_astat<0>(acc[PAR][0][j & 1], fb[sub & 1][j & 1], afr[0][kt * 4 + sub]);
+                        else mfma_astat<1>(acc[PAR][1][j & 1], fb[sub & 1][j & 1], afr[1][kt * 4 + sub]);
+                    }
+                    if (j < 2) {
+                        if (sub < 3) read_b1(kt & 3, sub + 1, j, fb[(sub + 1) & 1][j]);
+                        else read_b1((kt + 1) & 3, 0, j, fb[0][j]);
+                    } else if (j == 2) {
+#ifndef MSF2_DIAG_ASTAT_NOCOPY
+                        if (sub < 3) copy_piece((kt + 3) & 3, sub + 1);     // (the stage whose piece 0 went out in the k tile before)
+                        else copy_piece(kt & 3, 0);                         // stream tile + 4 goes into the slot just released
+#endif
+                        if (sub == 2) {
+                            if (kt == KT - NST) wnext = wrap_prev ? reinterpret_cast<const unsigned short*>(a.W) : wnext + tile_step;
+                            else wnext += 64;
+                        }
+                    } else if (sub == 3) {
+                        // bias of the two groups the NEXT k tile finishes (the next column tile's first, after the last k tile)
+                        if (kt < KT - 1) load_bias(bq[(kt + 1) & 1], (kt + 1) >> 1, ((kt + 1) & 1) * 2, nprev);
+                        else load_bias(bq[0], 0, 0, nprev + 128);
+                    }
+#ifndef MSF2_DIAG_ASTAT_NOEPI
                     epi_slot(par_tag, kt, sub * 4 + j);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if !defined(MSF2_DIAG_ASTAT_NOEPI) && !defined(MSF2_DIAG_ASTAT_NOSTORE)
             if (kt & 1) store_tile(kt >> 1, nprev);
+#endif
         }
     };
 
     // stage 0 has landed once at most the copies of the three younger stages are outstanding
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * D) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * D + 1) : "memory");
     __builtin_amdgcn_s_barrier();
     read_b(0, 0, fb[0]);
     load_bias(bq[0], 0, 0, 0);
