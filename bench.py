@@ -182,11 +182,14 @@ def roofline_record(model, prec_name, which, ms, flops, nl, B, T, traffic):
         gbytes = 3.0 * M * C * 2 / 1e9                                    # h, t in; h' out
         copy_ms = BF16_TCN_COPY_ONLY_MS_AT_255936_ROWS * M / 255936.0
     else:
-        name = "gemm_kernel_bf16_dma<ProjNT<1,0>> (token-shifted to_hidden|to_qk projection N=2176, bf16 MFMA 32x32x16)"
+        name = ("proj_astat_bf16_kernel<1,1> (token-shifted to_hidden|to_qk projection N=2176, activation rows resident in "
+                "registers, bf16 MFMA 32x32x16)")
         gbytes = (M * C + M * (4 * C + 128)) * 2 / 1e9                    # x in; [v|u|qk] out
         copy_ms = None
     hbm = gbytes / (ms * 1e-3)
-    return {"bound": "mfma", "binding_resource": "l2->lds operand copy path (neither roof)", "kernel": name,
+    binding = ("l2->lds operand copy path (neither roof)" if which == 0 else
+               "in-order issue of one wave per SIMD: fragment reads, weight copies and epilogue arithmetic add to the MFMA time (neither roof)")
+    return {"bound": "mfma", "binding_resource": binding, "kernel": name,
             "achieved": tf, "peak": PEAK_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA,
             "frac_mfma": tf / PEAK_BF16_MFMA, "frac_hbm": hbm / PEAK_HBM, "achieved_hbm_gb_s": hbm,
             "copy_only_bound_ms": copy_ms, "traffic": traffic, "launch_ms": ms, "launches_timed": nl}
@@ -335,9 +338,18 @@ def run_sweep(a, model, cfg, dev, rank, world, use_dist, stub, sync):
             allbuf = sw.gather_flat()
         return stats, allbuf
 
+    # a line on stderr now and then: a pass over the whole sweep takes minutes on one GPU (nothing else is printed meanwhile)
+    last_note = [time.perf_counter()]
+
+    def note(what):
+        if rank == 0 and time.perf_counter() - last_note[0] > 20.0:
+            last_note[0] = time.perf_counter()
+            print(f"[bench.py c5] {what}", file=sys.stderr, flush=True)
+
     sw.reset_stats()
     for w in range(W):                                           # untimed: the first W slices, and the exchange once
         sw.run_resident(model, chunks[w % K])
+        note(f"warm-up slice {w + 1} of {W} enqueued")
     if W:
         exchange()
     sw.reset_stats()
@@ -345,6 +357,7 @@ def run_sweep(a, model, cfg, dev, rank, world, use_dist, stub, sync):
     t0 = time.perf_counter()
     for k in range(K):
         sw.run_resident(model, chunks[k])
+        note(f"slice {k + 1} of {K} enqueued")
     sync()
     busy_mine = time.perf_counter() - t0                        # this rank's share separated
     stats, allbuf = exchange()
@@ -414,9 +427,15 @@ def run_sweep(a, model, cfg, dev, rank, world, use_dist, stub, sync):
     if a.host_copy_pass and not stub:
         # the same sweep from host memory: pinned staging, copies under compute, SI-SDR sums on the device
         from speech_separation_amd.parallel import separate_sharded
+        done = [0]
+
+        def model_noting(xb):
+            done[0] += 1
+            note(f"host-copy pass: batch {done[0]} enqueued")
+            return model(xb)
         fence()
         t0 = time.perf_counter()
-        separate_sharded(model, data.utterances, rank, world, max_batch=64, device=dev, references=data.references,
+        separate_sharded(model_noting, data.utterances, rank, world, max_batch=64, device=dev, references=data.references,
                          max_samples=int(budget_s * rate), lengths=data.lengths)
         fence()
         th = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)

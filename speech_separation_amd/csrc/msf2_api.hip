@@ -720,7 +720,7 @@ const char* msf2_strerror(int code) {
     }
 }
 int msf2_last_hip_error(void) { return g_last_hip_error; }
-int msf2_version(void) { return 3; }
+int msf2_version(void) { return 4; }
 int msf2_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(msf2_config);

@@ -69,3 +69,19 @@ def test_sharded_sweep_reduction_and_gather_on_rccl():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d == {"ok": True, "n": 5, "count": 5.0}
+
+
+def test_sweep_workload_collectives_on_rccl():
+    """bench.py --workload c5 (what N > 1 runs by default) with the process group formed over RCCL by ONE rank: the plan,
+    the resident staging, the SI-SDR reduction and the gather of every output run as they do on N ranks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c5", "--utterances", "24",
+                        "--steps", "3", "--warmup", "1", "--collectives-at-one-rank"],
+                       env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["scaling"] == "strong" and d["n_gpus"] == 1
+    assert d["utterances_in_statistic"] == 24.0 and d["outputs_finite"] and d["spot_check_rel_err_vs_alone"] <= 1e-5
+    # warm-up exchange (reduce + gather), two fences, the timed exchange, the gather of the rank times
+    assert d["collectives_per_rank"] == 2 + 2 + 2 + 1
+    assert d["lpt_imbalance"] == 1.0 and len(d["busy_s_per_rank"]) == 1
