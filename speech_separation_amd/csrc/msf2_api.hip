@@ -156,6 +156,17 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
         int loop = c.k.ncol_loop;
         ProjArgs al = a;
         al.store_aware = c.k.store_aware ? 1 : 0;
+        if constexpr (EPI == EPI_NORM && AMODE == A_PLAIN) {
+            // the same kernel with the folded-LayerNorm epilogue (per-row statistics, no positional term, bf16 output only):
+            // proj_in of the gated TCN block
+            const long wgs = (long)cdiv(c.S, 128) * c.B;
+            if (c.k.astat && a.K == 512 && a.N % 128 == 0 && a.N <= 2048 && a.out16 && !a.out && !a.out2 && !a.sq_part && a.rowstat &&
+                !a.bstat && !a.pe && a.act == 0 && a.c1 && a.c2 && (a.lda & 7) == 0 && (a.ldo & 7) == 0 && al16(a.A16) && al16(a.out16) &&
+                al16(a.W) && wgs >= c.cus) {
+                hipLaunchKernelGGL((proj_astat_bf16_kernel<A_PLAIN, ACT_NORM>), dim3(cdiv(c.S, 128), c.B), dim3(256), 0, c.st, al);
+                return 0;
+            }
+        }
         if constexpr (EPI == EPI_RS_BIAS_ACT) {
             // Activation rows resident in registers, weights streamed: one 4-wave workgroup per 128 rows walks every column
             // tile.  Needs a workgroup per CU at least (fewer: the tile forms below spread over the chip better), a bf16-only

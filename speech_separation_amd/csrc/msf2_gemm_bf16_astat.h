@@ -1,5 +1,6 @@
 // bf16 projection with the activation rows held in REGISTERS ("A-stationary"):
-//     out16[m, n] = act(rowscale[m] * sum_k A'[m, k] W[n, k] + bias[n]),   K = 512, N a multiple of 128.
+//     out16[m, n] = act(rowscale[m] * sum_k A'[m, k] W[n, k] + bias[n]),   K = 512, N a multiple of 128      (ACT 0 / 1 / 2), or
+//     out16[m, n] = rstd[m] * (sum_k A[m, k] W[n, k] - mean[m] * c2[n]) + c1[n]   (ACT_NORM: a folded LayerNorm, N <= 2048).
 //
 // One workgroup (4 waves, ONE per SIMD, so a wave may use the whole 512-entry register file) owns 128 token rows and
 // walks ALL column tiles of 128 outputs.  A wave keeps the MFMA fragments of its 64 rows x 512 k in registers for the
@@ -53,8 +54,11 @@ template <int TM> __device__ __forceinline__ void mfma_astat_first(f32x16& c, co
 }
 #endif
 
+constexpr int ACT_NORM = 16;      // epilogue kind: per-row (mean, rstd) from a.rowstat, per-column c1 / c2, no activation
+
 template <int AMODE, int ACT>
 __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs a) {
+    constexpr bool NORM = (ACT == ACT_NORM);
     constexpr int NST = 4, STAGE = 128 * 128;     // ring: 4 stages of 128 weight rows x 128 B (k tile of 64)
     constexpr int D = 4;                          // copies per wave and stage (16 of 1 KiB per stage)
     constexpr int KT = 8, KS = 32;                // k tiles and MFMA steps (k 16) for K = 512
@@ -68,11 +72,17 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     const bool interior = s0 + 128 <= S;
 
     // ---- bias vector -> LDS (read by the epilogue arithmetic as broadcast 16-byte reads) ----
-    for (int i = tid; i < a.N / 4; i += 256)
-        reinterpret_cast<float4*>(sbias)[i] = a.bias ? ld4(a.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < a.N / 4; i += 256) {
+        if constexpr (NORM) {
+            reinterpret_cast<float4*>(sbias)[i] = ld4(a.c1 + 4 * i);
+            reinterpret_cast<float4*>(sbias + MAXN / 2)[i] = ld4(a.c2 + 4 * i);
+        } else {
+            reinterpret_cast<float4*>(sbias)[i] = a.bias ? ld4(a.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 
     // ---- this lane's two token rows: scale, output address, activation fragments ----
-    float r0[2];
+    float r0[2], mu[2] = {0.f, 0.f};        // row scale (rstd of the folded norm), row mean
     char* orow[2];
     bool ok[2];
     u32x4_t afr[2][KS];
@@ -82,7 +92,8 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         ok[tm] = sr < S;
         const int s = min(sr, S - 1);                       // rows past the utterance end are clamped, never stored
         const long m = (long)b * S + s;
-        r0[tm] = a.rowstat ? a.rowstat[m] : 1.f;
+        if constexpr (NORM) { mu[tm] = a.rowstat[2 * m]; r0[tm] = a.rowstat[2 * m + 1]; }
+        else r0[tm] = a.rowstat ? a.rowstat[m] : 1.f;
         orow[tm] = reinterpret_cast<char*>(a.out16) + (m * a.ldo + wc * 64) * 2 + kh * 16;
         const unsigned short* arow = a.A16 + m * a.lda;
         // token shift: the first half of the features comes from the previous frame, zeros at frame 0
@@ -146,7 +157,8 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     f32x16 acc[2][2][2];
     bool st_ok[2] = {false, false};     // whether this lane stores its row of a finished tile (false while there is none)
     u32x2_t pk[4];
-    float4 bq[2][2];               // bias of the two accumulator groups finished per k tile: [k tile parity][group]
+    float4 bq[2][2];               // bias (c1) of the two accumulator groups finished per k tile: [k tile parity][group]
+    float4 bq2[2][2];              // ACT_NORM: c2 of the same groups
     float val[4] = {0.f, 0.f, 0.f, 0.f};
 
     // bias of groups g0, g0 + 1 of MFMA tile q of the column tile starting at nb (broadcast reads: two addresses per wave)
@@ -154,6 +166,15 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         const float* p = sbias + nb + wc * 64 + (q & 1) * 32 + 4 * kh;
         dst[0] = *reinterpret_cast<const float4*>(p + 8 * g0);
         dst[1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
+    };
+    // (both vectors of the folded norm; the plain epilogue has only the bias)
+    auto load_vecs = [&](int par, int q, int g0, int nb) __attribute__((always_inline)) {
+        load_bias(bq[par], q, g0, nb);
+        if constexpr (NORM) {
+            const float* p = sbias + MAXN / 2 + nb + wc * 64 + (q & 1) * 32 + 4 * kh;
+            bq2[par][0] = *reinterpret_cast<const float4*>(p + 8 * g0);
+            bq2[par][1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
+        }
     };
     // The arithmetic of one accumulator group (4 values of one row) takes the shadows of 8 MFMAs, one phase per MFMA, each
     // phase a handful of mutually INDEPENDENT instructions (a wave alone on its SIMD issues in order: an instruction that
@@ -173,9 +194,18 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         if (ph == 0) {
             asm volatile("" : "+v"(r0[tm]));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) val[e] = r0[tm] * acc[PP][tm][tn][4 * g + e] + f4get(bq[kt & 1][gi], e);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NORM) val[e] = acc[PP][tm][tn][4 * g + e] - mu[tm] * f4get(bq2[kt & 1][gi], e);
+                else val[e] = r0[tm] * acc[PP][tm][tn][4 * g + e] + f4get(bq[kt & 1][gi], e);
+            }
             asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
         } else if (ph == 1) {
+            if constexpr (NORM) {
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = r0[tm] * val[e] + f4get(bq[kt & 1][gi], e);
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+            }
             if constexpr (SIG) {
                 asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
 #pragma unroll
@@ -290,8 +320,8 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                         }
                     } else if (sub == 3) {
                         // bias of the two groups the NEXT k tile finishes (the next column tile's first, after the last k tile)
-                        if (kt < KT - 1) load_bias(bq[(kt + 1) & 1], (kt + 1) >> 1, ((kt + 1) & 1) * 2, nprev);
-                        else load_bias(bq[0], 0, 0, nprev + 128);
+                        if (kt < KT - 1) load_vecs((kt + 1) & 1, (kt + 1) >> 1, ((kt + 1) & 1) * 2, nprev);
+                        else load_vecs(0, 0, 0, nprev + 128);
                     }
 #ifndef MSF2_DIAG_ASTAT_NOEPI
                     epi_slot(par_tag, kt, sub * 4 + j);
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * D + 1) : "memory");
     __builtin_amdgcn_s_barrier();
     read_b(0, 0, fb[0]);
-    load_bias(bq[0], 0, 0, 0);
+    load_vecs(0, 0, 0, 0);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -328,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     if (NT & 1) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            load_bias(bq[kt & 1], kt >> 1, (kt & 1) * 2, nlast);
+            load_vecs(kt & 1, kt >> 1, (kt & 1) * 2, nlast);
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P1(), kt, m);    // (the tag names the set that would FOLLOW: the slot reads set 0)
             if (kt & 1) store_tile(kt >> 1, nlast);
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     } else {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            load_bias(bq[kt & 1], kt >> 1, (kt & 1) * 2, nlast);
+            load_vecs(kt & 1, kt >> 1, (kt & 1) * 2, nlast);
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P0(), kt, m);
             if (kt & 1) store_tile(kt >> 1, nlast);
