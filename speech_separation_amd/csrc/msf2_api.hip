@@ -87,6 +87,7 @@ struct Knobs {
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
     bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
+    int stage_a_split_below = -1;  // "stage_a_split_below": TCN stage A runs its quarter-frames form below this many blocks (-1: default rule)
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
     char g4[16] = "0";          //   'a' + EPI for the token-shifted operand, '0' + EPI otherwise
@@ -108,16 +109,16 @@ static bool small_grid(const Ctx& c, int N) {
     if (!c.k.narrow || (N % 128) != 0) return false;
     const long t = (long)cdiv(N, 128) * cdiv(c.S, 128) * c.B;
     if (c.k.narrow_below >= 0) return t < c.k.narrow_below;
-    // measured on 4-s utterances, batch 1..4 (128 / 256 / 384 / 512 tiles for N = 512): fp32 faster in the small-grid form up to
-    // 384 tiles (two workgroups per CU: 512 slots), bf16 up to 256
     if (c.prec == MSF2_PREC_BF16) return t < c.cus + 1;
-    const long round = 2L * c.cus;       // resident 128 x 128 fp32 tiles: two workgroups per CU
-    if (t < round) return true;
-    // fp32, a few rounds of 512 resident tiles: the form whose last round is fuller (544 tiles of the N = 2176 projection at
-    // 1 x 4 s are two rounds of 128-wide tiles, the second nearly empty, but 2.1 rounds of half-size tiles: -2 % per forward)
-    if (t >= 8 * round) return false;
-    const long wide_idle = cdiv(t, round) * round - t, narrow_idle = (cdiv(2 * t, round) * round - 2 * t) / 2;
-    return narrow_idle + t / 16 < wide_idle;
+    // fp32: a CU works through its share of the tiles at about one 128 x 128 tile per unit of time whether one or two are
+    // resident, so the wide form costs ceil(t / CUs) units and the half-size form ceil(2 t / CUs) / 2 at ~6 % less per-tile
+    // efficiency; at or below one tile per CU the half-size form also wins, by having two workgroups per CU to overlap.
+    // Measured at batch 1: 4 s, 8 s (t <= CUs), 10 s and 12 s (316 / 376 tiles for N = 512: 2 units against 1.5) faster in
+    // the small-grid form by 3..11 % per forward; 15 s (472 tiles: 2 against 2) slower by 3 %; N = 2176 at 4 s (544 tiles:
+    // 3 against 2.5) faster.
+    if (t <= c.cus) return true;
+    if (t >= 16L * c.cus) return false;
+    return 0.53 * (double)cdiv(2 * t, (long)c.cus) < (double)cdiv(t, (long)c.cus);
 }
 
 // launch the fp32 or the bf16 build of a contraction
@@ -429,11 +430,12 @@ static TcnWs tcn_ws(Arena& ar, int B, int S, int C, int prec) {
 }
 
 // Frames per thread of a TCN stage A launch.  `full` frames (32 per block) normally; a quarter of that when the launch
-// would give fewer than two blocks per CU (one or two short utterances per call): four times the blocks, each thread
+// would give less than one block per CU (one short utterance per call): four times the blocks, each thread
 // re-reading two neighbour rows per 2..4 frames instead of per 8..16 -- from a tensor that then fits the caches.
 static int stage_a_frames_per_thread(const Ctx& c, int full, int rows_per_block) {
     const long blocks = (long)cdiv(c.S, full * rows_per_block) * c.B;
-    return (c.k.narrow && blocks < 2 * c.cus && full >= 4) ? full / 4 : full;
+    const long below = c.k.stage_a_split_below >= 0 ? c.k.stage_a_split_below : c.cus;   // measured at batch 1: faster up to 6 s (188 blocks), even at 8 s (250), slower from 10 s (313)
+    return (c.k.narrow && blocks < below && full >= 4) ? full / 4 : full;
 }
 
 // returns the number of partial-sum entries (blocks per utterance) the launch wrote
@@ -787,6 +789,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
+    else if (!strcmp(name, "stage_a_split_below")) k.stage_a_split_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
     else if (!strcmp(name, "store_aware")) k.store_aware = atoi(value) != 0;
     else if (!strcmp(name, "astat")) k.astat = atoi(value) != 0;

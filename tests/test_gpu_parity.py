@@ -457,11 +457,11 @@ def test_bf16_kernel_choices_agree():
         assert torch.equal(outs_p[name], outs_p["default"]), name + " (projection)"
 
 
-@pytest.mark.parametrize("B,T", [(8, 32000), (11, 20011)])
+@pytest.mark.parametrize("B,T", [(8, 32000), (11, 20011), (40, 8000)])
 def test_bf16_register_resident_projection_agrees(B, T):
-    """The bf16 K = 512 projections with a bias / activation epilogue (token-shifted to_hidden | to_qk, N = 2176, and the
-    gate of the gated TCN block) run on the kernel that keeps the activation rows in registers and streams only the
-    weights once a call has a workgroup per CU.  Same arithmetic in the same order per output element as the tile
+    """The bf16 K = 512 projections with a bf16-only output (token-shifted to_hidden | to_qk, N = 2176; the gate and proj_in
+    of the gated TCN block) run on the kernel that keeps the activation rows in registers and streams only the
+    weights once a call has a workgroup per CU (the third case: a batch of the segmented path's 1-s windows).  Same arithmetic in the same order per output element as the tile
     kernels it replaces: the forward must not depend on which one ran (2 layers at the real widths; the second length
     leaves a partial row tile of 3 rows)."""
     cfg2 = type(FULL_8K)(num_layers=2)
