@@ -224,6 +224,21 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
     for (int o = 0; o < DW_TS; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xb = x + (long)b * S * ldx + 4 * cq;
     const unsigned short* xb16 = reinterpret_cast<const unsigned short*>(x) + (long)b * S * ldx + 4 * cq;
+    float* yb = y + (long)b * S * ldy + 4 * cq;
+    // bf16 input: every load of the tile is issued before the first multiply -- the 32 input rows (8 bytes per lane) and, when
+    // accumulating, the 16 previous result rows straight into the accumulators -- so that a wave has its whole tile in flight
+    // at once (64 + 64 registers) instead of waiting on the rows in the order the arithmetic consumes them.
+    uint2 raw[IN16 ? DW_TS + 16 : 1];
+    if constexpr (IN16) {
+#pragma unroll
+        for (int r = -8; r < DW_TS + 8; ++r)
+            raw[r + 8] = *reinterpret_cast<const uint2*>(xb16 + (long)min(max(s0 + r, 0), S - 1) * ldx);
+        if (accumulate) {
+#pragma unroll
+            for (int o = 0; o < DW_TS; ++o) acc[o] = *reinterpret_cast<const float4*>(yb + (long)min(s0 + o, S - 1) * ldy);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = -8; r < DW_TS + 8; ++r) {
         const int s = s0 + r;
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
         const float inb = (s >= 0 && s < S) ? 1.f : 0.f;
         float4 xv;
         if constexpr (IN16) {
-            const uint2 hq = *reinterpret_cast<const uint2*>(xb16 + (long)min(max(s, 0), S - 1) * ldx);
+            const uint2 hq = raw[r + 8];
             xv = make_float4(__builtin_bit_cast(float, hq.x << 16), __builtin_bit_cast(float, hq.x & 0xffff0000u),
                              __builtin_bit_cast(float, hq.y << 16), __builtin_bit_cast(float, hq.y & 0xffff0000u));
         } else {
@@ -249,11 +264,10 @@ __global__ __launch_bounds__(128) void dwconv17_kernel(const float* __restrict__
             if (r == o) { acc[o].x += xv.x; acc[o].y += xv.y; acc[o].z += xv.z; acc[o].w += xv.w; }
         }
     }
-    float* yb = y + (long)b * S * ldy + 4 * cq;
 #pragma unroll
     for (int o = 0; o < DW_TS; ++o) {
         const int s = s0 + o;
-        if (accumulate) {      // (uniform) previous value of the row, from the clamped row like the inputs
+        if (!IN16 && accumulate) {      // (uniform) previous value of the row, from the clamped row like the inputs
             const float4 p = *reinterpret_cast<const float4*>(yb + (long)min(s, S - 1) * ldy);
             acc[o].x += p.x; acc[o].y += p.y; acc[o].z += p.z; acc[o].w += p.w;
         }
