@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "msf2_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("msf2_common.h", "msf2_gemm.h", "msf2_gemm_bf16.h", "msf2_gemm_bf16_astat.h", "msf2_attn_fused.h", "msf2_ops.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("msf2_common.h", "msf2_gemm.h", "msf2_gemm_bf16.h", "msf2_gemm_bf16_astat.h", "msf2_attn_fused.h", "msf2_linkv_bf16.h", "msf2_ops.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "msf2.h")]
 OUT = os.path.join(HERE, "lib", "libmsf2.so")
 

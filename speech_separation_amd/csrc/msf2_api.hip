@@ -12,6 +12,7 @@
 #include "msf2_gemm_bf16.h"
 #include "msf2_gemm_bf16_astat.h"
 #include "msf2_attn_fused.h"
+#include "msf2_linkv_bf16.h"
 #include "msf2_ops.h"
 
 namespace msf2 {
@@ -87,6 +88,7 @@ struct Knobs {
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
     bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
+    bool linkv_dma = true;      // "linkv_dma": bf16 key/value summary on the global -> LDS kernel with transposing reads (0: register-staged tile kernel)
     int stage_a_split_below = -1;  // "stage_a_split_below": TCN stage A runs its quarter-frames form below this many blocks (-1: default rule)
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
     char g3[16] = "a";          // "geom3" / "geom4": projections that take the 3- / 4-workgroup geometries,
@@ -365,7 +367,10 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
     const float* lin_k = w.q4 + 3 * M * MSF2_QK_DIM;
     {
         LinKVArgs a = {lin_k, hsrc, ldhu, w.part, c.S, 2 * E, w.chunk};
-        if (hu16) launch_gemm<LinKVT<true>>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
+        if (hu16 && c.k.linkv_dma && (2 * E) % 256 == 0) {     // bf16 mode: tiles global -> LDS as they lie, both fragments through the transposing LDS read
+            LinKV16Args a16 = {reinterpret_cast<const unsigned short*>(lin_k), hu16, ldhu, w.part, c.S, 2 * E, w.chunk};
+            hipLaunchKernelGGL(linkv_bf16_kernel, dim3(2 * E / 256, w.nsplit, c.B), dim3(512), 0, c.st, a16);
+        } else if (hu16) launch_gemm<LinKVT<true>>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
         else launch_gemm<LinKV>(c, dim3(cdiv(2 * E, BN), w.nsplit, c.B), a);
         const long per_b = (long)MSF2_QK_DIM * 2 * E, total = per_b * c.B;
         hipLaunchKernelGGL(kv_finalize_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, c.st, w.part, w.kv, w.nsplit, per_b, c.S, total);
@@ -789,6 +794,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
+    else if (!strcmp(name, "linkv_dma")) k.linkv_dma = atoi(value) != 0;
     else if (!strcmp(name, "stage_a_split_below")) k.stage_a_split_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;
     else if (!strcmp(name, "store_aware")) k.store_aware = atoi(value) != 0;

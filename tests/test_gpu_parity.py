@@ -481,6 +481,31 @@ def test_bf16_register_resident_projection_agrees(B, T):
     assert torch.equal(outs[b"1"], outs[b"0"])
 
 
+@pytest.mark.parametrize("B,T", [(1, 32000), (3, 20011), (5, 4000), (8, 32000)])
+def test_bf16_key_value_summary_kernels_agree(B, T):
+    """bf16 mode computes the linear-attention key/value summary (lin_k^T [v | u] over time, reference
+    mossformer2_block.py:318-322) with a kernel that copies both operands global -> LDS as they lie and transposes them in
+    the LDS read; the register-staged tile kernel it replaces stays selectable.  Same bf16 products, summed by the same MFMA
+    instruction in the same order over the same time chunks: the forward of a 2-layer full-width model must be
+    bit-identical between the two.  The shapes cover 16 time chunks with a partial last tile, a batch with a ragged
+    length, fewer frames than one chunk, and one chunk per utterance."""
+    cfg2 = type(FULL_8K)(num_layers=2)
+    m = MossFormerHIP(cfg2, compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg2, 0).items()})
+    x = torch.from_numpy(synth_batch(B, T, seed0=5)).to(DEV)
+    lib = _lib.load()
+    outs = {}
+    for val in (b"1", b"0"):
+        _lib.check(lib.msf2_debug_kernel_choice(None, None))
+        _lib.check(lib.msf2_debug_kernel_choice(b"linkv_dma", val))
+        try:
+            outs[val] = torch.stack(m(x), 0).cpu().numpy()
+        finally:
+            _lib.check(lib.msf2_debug_kernel_choice(None, None))
+    assert np.isfinite(outs[b"1"]).all() and np.abs(outs[b"1"]).max() > 0
+    assert np.array_equal(outs[b"1"], outs[b"0"])
+
+
 def test_bf16_batch_independence():
     """bf16 mode, full model: an utterance gives the same waveform alone and inside a batch of 12, up to
     bf16 rounding noise: the linear-attention summary is split over time in a batch-dependent number of
