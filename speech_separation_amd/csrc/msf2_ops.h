@@ -512,16 +512,19 @@ __global__ __launch_bounds__(256) void tcn_stage_a_bf16_kernel(const unsigned sh
     const int T = blockIdx.x * nf + fo;
     const int base = (T / dil) * (NIT * dil) + (T % dil);
     const int c = 8 * cq;
-    float wk[3][8], bs[8];
+    // arithmetic on channel pairs (2 q, 2 q + 1) -- the two halves of one packed word -- so that it maps onto the packed
+    // fp32 instructions: per pair 3 fused multiply-adds, the SiLU (2 exponentials, 2 reciprocals, 3 packed operations),
+    // 2 packed operations for the statistics and one conversion
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 wk[3][4], bs[4];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float4 lo = *reinterpret_cast<const float4*>(w + k * C + c), hi = *reinterpret_cast<const float4*>(w + k * C + c + 4);
-        wk[k][0] = lo.x; wk[k][1] = lo.y; wk[k][2] = lo.z; wk[k][3] = lo.w;
-        wk[k][4] = hi.x; wk[k][5] = hi.y; wk[k][6] = hi.z; wk[k][7] = hi.w;
+        wk[k][0] = f2{lo.x, lo.y}; wk[k][1] = f2{lo.z, lo.w}; wk[k][2] = f2{hi.x, hi.y}; wk[k][3] = f2{hi.z, hi.w};
     }
     {
         const float4 lo = *reinterpret_cast<const float4*>(bias + c), hi = *reinterpret_cast<const float4*>(bias + c + 4);
-        bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w; bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
+        bs[0] = f2{lo.x, lo.y}; bs[1] = f2{lo.z, lo.w}; bs[2] = f2{hi.x, hi.y}; bs[3] = f2{hi.z, hi.w};
     }
     const unsigned short* hb = h16 + (long)b * S * C + c;
     uint4 x[NIT + 2];        // rows base + (j - 1) dil, j = 0 .. NIT + 1
@@ -530,35 +533,48 @@ __global__ __launch_bounds__(256) void tcn_stage_a_bf16_kernel(const unsigned sh
         const int s = min(max(base + (j - 1) * dil, 0), S - 1);
         x[j] = *reinterpret_cast<const uint4*>(hb + (long)s * C);
     }
-    float sum = 0.f, sq = 0.f;
+    // a row outside the utterance is a zero tap: cleared as packed words (4 operations per row instead of a 0/1 factor on
+    // each of its 16 uses); such a row is the centre only of frames that are not stored
+#pragma unroll
+    for (int j = 0; j < NIT + 2; ++j) {
+        const int r = base + (j - 1) * dil;
+        const unsigned keep = (r >= 0 && r < S) ? 0xffffffffu : 0u;
+        x[j].x &= keep; x[j].y &= keep; x[j].z &= keep; x[j].w &= keep;
+    }
+    f2 sum2 = {0.f, 0.f}, sq2 = {0.f, 0.f};
+    // each row is unpacked once and serves as the right, centre and left tap of three consecutive frames
+    auto unpack = [](const uint4& r, f2 (&f)[4]) __attribute__((always_inline)) {
+        const unsigned wds[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = f2{__builtin_bit_cast(float, wds[q] << 16), __builtin_bit_cast(float, wds[q] & 0xffff0000u)};
+    };
+    f2 m_[4], z_[4], p_[4];
+    unpack(x[0], m_);
+    unpack(x[1], z_);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
         const int s = base + j * dil;
-        const float fm = (s - dil >= 0) ? 1.f : 0.f, fp = (s + dil < S) ? 1.f : 0.f;
-        const unsigned am[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
-        const unsigned a0[4] = {x[j + 1].x, x[j + 1].y, x[j + 1].z, x[j + 1].w};
-        const unsigned ap[4] = {x[j + 2].x, x[j + 2].y, x[j + 2].z, x[j + 2].w};
-        float v[8];
+        unpack(x[j + 2], p_);
+        f2 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int hbit = 0; hbit < 2; ++hbit) {
-                const int e = 2 * q + hbit;
-                const float m_ = __builtin_bit_cast(float, hbit ? (am[q] & 0xffff0000u) : (am[q] << 16)) * fm;
-                const float z_ = __builtin_bit_cast(float, hbit ? (a0[q] & 0xffff0000u) : (a0[q] << 16));
-                const float p_ = __builtin_bit_cast(float, hbit ? (ap[q] & 0xffff0000u) : (ap[q] << 16)) * fp;
-                v[e] = silu_f(wk[0][e] * m_ + wk[1][e] * z_ + wk[2][e] * p_ + bs[e]);
-            }
+            const f2 y = __builtin_elementwise_fma(wk[0][q], m_[q], __builtin_elementwise_fma(wk[1][q], z_[q], __builtin_elementwise_fma(wk[2][q], p_[q], bs[q])));
+            const f2 t2 = y * -1.44269504088896341f;
+            const f2 d = f2{__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)} + 1.0f;
+            v[q] = y * f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
         }
         if (s < S) {
             uint4 pk;
-            pk.x = pk_bf16_pair(v[0], v[1]); pk.y = pk_bf16_pair(v[2], v[3]);
-            pk.z = pk_bf16_pair(v[4], v[5]); pk.w = pk_bf16_pair(v[6], v[7]);
+            pk.x = pk_bf16_pair(v[0].x, v[0].y); pk.y = pk_bf16_pair(v[1].x, v[1].y);
+            pk.z = pk_bf16_pair(v[2].x, v[2].y); pk.w = pk_bf16_pair(v[3].x, v[3].y);
             *reinterpret_cast<uint4*>(t16 + ((long)b * S + s) * C + c) = pk;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sum += v[e]; sq += v[e] * v[e]; }
+            for (int q = 0; q < 4; ++q) { sum2 += v[q]; sq2 = __builtin_elementwise_fma(v[q], v[q], sq2); }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { m_[q] = z_[q]; z_[q] = p_[q]; }
     }
+    const float sum = sum2.x + sum2.y, sq = sq2.x + sq2.y;
     write_partial(sum, sq, part + ((long)b * gridDim.x + blockIdx.x) * 2, red);
 }
 
