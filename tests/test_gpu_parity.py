@@ -488,7 +488,7 @@ def test_bf16_key_value_summary_kernels_agree(B, T):
     the LDS read; the register-staged tile kernel it replaces stays selectable.  Same bf16 products, summed by the same MFMA
     instruction in the same order over the same time chunks: the forward of a 2-layer full-width model must be
     bit-identical between the two.  The shapes cover 16 time chunks with a partial last tile, a batch with a ragged
-    length, fewer frames than one chunk, and one chunk per utterance."""
+    length, fewer frames than one chunk, and 8 chunks per utterance."""
     cfg2 = type(FULL_8K)(num_layers=2)
     m = MossFormerHIP(cfg2, compute_device=DEV, precision=BF)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg2, 0).items()})
