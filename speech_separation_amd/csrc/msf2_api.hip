@@ -658,7 +658,9 @@ static int run_gated_fsmn(const Ctx& c, const FsmnWs& w, const float* x, const m
 static void run_decoder(const Ctx& c, const float* sep, const float* dec_w, float* fv, float* est, int C) {
     int grid = cdiv(c.M, 4);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(decoder_frames_kernel, dim3(grid), dim3(256), (size_t)C * 20 * sizeof(float), c.st, sep, dec_w, fv, c.M, C);
+    if (C == 512) hipLaunchKernelGGL(decoder_frames_reg_kernel<2>, dim3(grid), dim3(256), 0, c.st, sep, dec_w, fv, c.M);
+    else if (C == 256) hipLaunchKernelGGL(decoder_frames_reg_kernel<1>, dim3(grid), dim3(256), 0, c.st, sep, dec_w, fv, c.M);
+    else hipLaunchKernelGGL(decoder_frames_kernel, dim3(grid), dim3(256), (size_t)C * 20 * sizeof(float), c.st, sep, dec_w, fv, c.M, C);
     const long n = (long)c.B * c.T;
     hipLaunchKernelGGL(decoder_ola_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c.st, fv, est, c.B, c.S, c.T);
 }
