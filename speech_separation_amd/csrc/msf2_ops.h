@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256) void decoder_frames_kernel(const float* __rest
 // The same product for C a multiple of 256 with the weights in registers: a lane owns channels 4 l .. 4 l + 3 of each
 // 256-channel slab (16-byte loads, a whole row of 512 channels in two wave loads) and keeps W[c][0..15] of its channels in
 // NV * 64 registers, so a frame costs NV loads and NV * 32 packed multiply-adds per lane and no LDS traffic; the 16 sums
-// over the 64 lanes take 17 exchanges (rows16_sum) instead of 96.  Two frames per iteration keep 2 NV loads in flight per lane.
+// over the 64 lanes take 17 exchanges (rows16_sum) instead of 96.  Four frames per iteration keep 4 NV loads in flight per lane.
 template <int NV>      // NV = C / 256
 __global__ __launch_bounds__(256) void decoder_frames_reg_kernel(const float* __restrict__ sep, const float* __restrict__ w,
                                                                  float* __restrict__ fv, long M) {
@@ -716,34 +716,34 @@ __global__ __launch_bounds__(256) void decoder_frames_reg_kernel(const float* __
 #pragma unroll
             for (int j = 0; j < 4; ++j) wr[v][ch][j] = *reinterpret_cast<const float4*>(w + (long)(256 * v + 4 * lane + ch) * 16 + 4 * j);
     const long nw = (long)gridDim.x * 4;
-    for (long m0 = 2 * ((long)blockIdx.x * 4 + wave); m0 < M; m0 += 2 * nw) {
-        const long m1 = (m0 + 1 < M) ? m0 + 1 : m0;       // (the odd last frame is computed twice and stored once)
-        float4 xa[NV], xb[NV];
+    constexpr int NF = 4;      // frames per iteration
+    for (long m0 = NF * ((long)blockIdx.x * 4 + wave); m0 < M; m0 += NF * nw) {
+        float4 xs[NF][NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            xa[v] = *reinterpret_cast<const float4*>(sep + m0 * C + 256 * v + 4 * lane);
-            xb[v] = *reinterpret_cast<const float4*>(sep + m1 * C + 256 * v + 4 * lane);
+        for (int f = 0; f < NF; ++f) {
+            const long m = (m0 + f < M) ? m0 + f : M - 1;       // (frames past the end are computed from the last one and not stored)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xs[f][v] = *reinterpret_cast<const float4*>(sep + m * C + 256 * v + 4 * lane);
         }
-        float aa[16], ab[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { aa[k] = 0.f; ab[k] = 0.f; }
+        for (int f = 0; f < NF; ++f) {
+            float acc[16];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const float ca[4] = {xa[v].x, xa[v].y, xa[v].z, xa[v].w}, cb[4] = {xb[v].x, xb[v].y, xb[v].z, xb[v].w};
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
+            for (int v = 0; v < NV; ++v) {
+                const float cx[4] = {xs[f][v].x, xs[f][v].y, xs[f][v].z, xs[f][v].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 wv = wr[v][ch][j];
-                    aa[4 * j + 0] += ca[ch] * wv.x; aa[4 * j + 1] += ca[ch] * wv.y; aa[4 * j + 2] += ca[ch] * wv.z; aa[4 * j + 3] += ca[ch] * wv.w;
-                    ab[4 * j + 0] += cb[ch] * wv.x; ab[4 * j + 1] += cb[ch] * wv.y; ab[4 * j + 2] += cb[ch] * wv.z; ab[4 * j + 3] += cb[ch] * wv.w;
-                }
-        }
-        rows16_sum(aa, lane);
-        rows16_sum(ab, lane);
-        if (lane < 16) {
-            fv[m0 * 16 + rev4(lane)] = aa[0];
-            if (m1 != m0) fv[m1 * 16 + rev4(lane)] = ab[0];
+                for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 wv = wr[v][ch][j];
+                        acc[4 * j + 0] = __builtin_fmaf(cx[ch], wv.x, acc[4 * j + 0]); acc[4 * j + 1] = __builtin_fmaf(cx[ch], wv.y, acc[4 * j + 1]);
+                        acc[4 * j + 2] = __builtin_fmaf(cx[ch], wv.z, acc[4 * j + 2]); acc[4 * j + 3] = __builtin_fmaf(cx[ch], wv.w, acc[4 * j + 3]);
+                    }
+            }
+            rows16_sum(acc, lane);
+            if (lane < 16 && m0 + f < M) fv[(m0 + f) * 16 + rev4(lane)] = acc[0];
         }
     }
 }
