@@ -506,6 +506,33 @@ def test_bf16_key_value_summary_kernels_agree(B, T):
     assert np.array_equal(outs[b"1"], outs[b"0"])
 
 
+def test_bf16_equivalent_kernel_forms_on_ragged_shapes():
+    """The bit-identical kernel pairs of the bf16 mode (register-resident-activation projections vs tile kernels, key/value
+    summary global -> LDS kernel vs tile kernel) on a dozen seeded shapes with odd lengths: frame counts just below, at and
+    just above multiples of the 32-frame k tile, the 128-row tile and the 256-frame group, batches 1 .. 9."""
+    cfg2 = type(FULL_8K)(num_layers=2)
+    m = MossFormerHIP(cfg2, compute_device=DEV, precision=BF)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(cfg2, 0).items()})
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    shapes = [(1, 8 * 255 + 16), (1, 8 * 256 + 16), (2, 8 * 257 + 16), (9, 8 * 127 + 16), (3, 8 * 128 + 23), (1, 8 * 1023 + 16),
+              (2, 8 * 1024 + 16), (1, 8 * 1025 + 19)]
+    shapes += [(int(rng.integers(1, 10)), int(rng.integers(1600, 40000))) for _ in range(4)]
+    for B, T in shapes:
+        x = torch.from_numpy(synth_batch(B, T, seed0=13)).to(DEV)
+        for knob in (b"astat", b"linkv_dma"):
+            outs = {}
+            for val in (b"1", b"0"):
+                _lib.check(lib.msf2_debug_kernel_choice(None, None))
+                _lib.check(lib.msf2_debug_kernel_choice(knob, val))
+                try:
+                    outs[val] = torch.stack(m(x), 0)
+                finally:
+                    _lib.check(lib.msf2_debug_kernel_choice(None, None))
+            assert torch.isfinite(outs[b"1"]).all(), (B, T, knob)
+            assert torch.equal(outs[b"1"], outs[b"0"]), (B, T, knob)
+
+
 def test_bf16_batch_independence():
     """bf16 mode, full model: an utterance gives the same waveform alone and inside a batch of 12, up to
     bf16 rounding noise: the linear-attention summary is split over time in a batch-dependent number of
