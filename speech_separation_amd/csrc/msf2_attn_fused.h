@@ -264,9 +264,7 @@ __global__ __launch_bounds__(512, 1) void attn_fused_bf16_kernel(const AttnFused
             r.z = (au[i].z * v.z) * sigmoid_f(av[i].z * u.z);
             r.w = (au[i].w * v.w) * sigmoid_f(av[i].w * u.w);
             float ssq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-            ssq += __shfl_xor(ssq, 1, 64);
-            ssq += __shfl_xor(ssq, 2, 64);
-            ssq += __shfl_xor(ssq, 4, 64);
+            ssq = sum8_dpp(ssq);
             if (ok[i] && valid) {
                 uint2 h;
                 h.x = pk_bf16_2(r.x, r.y);

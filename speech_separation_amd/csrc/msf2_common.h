@@ -55,6 +55,15 @@ __device__ __forceinline__ unsigned pk_bf16_pair(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
 }
 
+// Sum over each aligned group of 8 lanes, delivered to all 8, by three DPP adds (quad_perm [1,0,3,2], [2,3,0,1], then
+// row_half_mirror pairing the two quads): the same additions as xor-shuffles by 1, 2, 4, without the LDS crossbar
+// (__shfl_xor is a ds_bpermute_b32: ~100 cycles of latency per step of the chain).
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

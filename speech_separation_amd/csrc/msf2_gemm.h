@@ -730,9 +730,7 @@ struct ProjNT {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float t = ssq[i];
-                        t += __shfl_xor(t, 1, 64);
-                        t += __shfl_xor(t, 2, 64);
-                        t += __shfl_xor(t, 4, 64);
+                        t = sum8_dpp(t);
                         if (rc == 0 && ok[i] && slab < np) a.sq_part[(long)mrow[i] * np + slab] = t;
                     }
                 }
@@ -1179,9 +1177,7 @@ struct AttnOutT {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float t = ssq[i];
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
+                t = sum8_dpp(t);
                 if (rc == 0 && ok[i]) a.sq_part[(long)mrow[i] * np + jt] = t;
             }
         }
