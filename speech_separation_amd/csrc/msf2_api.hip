@@ -88,6 +88,7 @@ struct Knobs {
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
     bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
+    bool astat_k1024 = true;    // "astat_k1024": the K = 1024 projection (to_out) on the register-resident-activation kernel
     bool linkv_dma = true;      // "linkv_dma": bf16 key/value summary on the global -> LDS kernel with transposing reads (0: register-staged tile kernel)
     int stage_a_split_below = -1;  // "stage_a_split_below": TCN stage A runs its quarter-frames form below this many blocks (-1: default rule)
     bool narrow = true;         // "narrow": 64-column tiles for fp32 projections whose 128-wide tiling cannot fill the chip
@@ -181,6 +182,14 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
                 if (a.act == 1) hipLaunchKernelGGL((proj_astat_bf16_kernel<AMODE, 1>), g, dim3(256), 0, c.st, al);
                 else hipLaunchKernelGGL((proj_astat_bf16_kernel<AMODE, 2>), g, dim3(256), 0, c.st, al);
                 return 0;
+            }
+            // K = 1024 (to_out of a FLASH layer): a wave holds 32 rows x 1024 k
+            if constexpr (AMODE == A_PLAIN) {
+                if (c.k.astat && c.k.astat_k1024 && a.K == 1024 && a.N % 128 == 0 && a.N <= 4096 && a.out16 && !a.out && !a.out2 && a.act == 1 &&
+                    (a.lda & 7) == 0 && (a.ldo & 7) == 0 && al16(a.A16) && al16(a.out16) && al16(a.W) && wgs >= c.cus) {
+                    hipLaunchKernelGGL((proj_astat_bf16_kernel<A_PLAIN, 1, 1024>), dim3(cdiv(c.S, 128), c.B), dim3(256), 0, c.st, al);
+                    return 0;
+                }
             }
         }
         if constexpr (!P::PAIRED && AMODE == A_PLAIN) {
@@ -796,6 +805,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
+    else if (!strcmp(name, "astat_k1024")) k.astat_k1024 = atoi(value) != 0;
     else if (!strcmp(name, "linkv_dma")) k.linkv_dma = atoi(value) != 0;
     else if (!strcmp(name, "stage_a_split_below")) k.stage_a_split_below = atoi(value);
     else if (!strcmp(name, "own_stats")) k.own_stats = atoi(value) != 0;

@@ -56,17 +56,29 @@ template <int TM> __device__ __forceinline__ void mfma_astat_first(f32x16& c, co
 
 constexpr int ACT_NORM = 16;      // epilogue kind: per-row (mean, rstd) from a.rowstat, per-column c1 / c2, no activation
 
-template <int AMODE, int ACT>
+// KDIM = 512: 2 x 2 waves, a wave holds 64 rows x 512 k (two row tiles) and finishes 64 of a column tile's 128 outputs.
+// KDIM = 1024: 4 x 1 waves, a wave holds 32 rows x 1024 k (one row tile) and finishes all 128 outputs of the column tile
+// (four weight fragments per MFMA step instead of two; twice the k tiles per column tile, so the arithmetic of the previous
+// tile has two MFMA shadows per phase).
+template <int AMODE, int ACT, int KDIM = 512>
 __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs a) {
+    static_assert(KDIM == 512 || KDIM == 1024, "a wave holds 256 registers of activation fragments");
+    static_assert(KDIM == 512 || AMODE == A_PLAIN, "the token shift is built for K = 512");
     constexpr bool NORM = (ACT == ACT_NORM);
     constexpr int NST = 4, STAGE = 128 * 128;     // ring: 4 stages of 128 weight rows x 128 B (k tile of 64)
     constexpr int D = 4;                          // copies per wave and stage (16 of 1 KiB per stage)
-    constexpr int KT = 8, KS = 32;                // k tiles and MFMA steps (k 16) for K = 512
+    constexpr int KT = KDIM / 64, KS = KDIM / 16; // k tiles and MFMA steps (k 16)
+    constexpr int TMW = (KDIM == 512) ? 2 : 1;    // row tiles (32 rows) per wave
+    constexpr int TNW = 4 / TMW;                  // MFMA column tiles (32 columns) per wave and column tile
+    constexpr int WCN = TMW;                      // waves side by side: 2 (K = 512) or 1
+    constexpr int KPQ = KT / 4;                   // k tiles per finished MFMA tile of the previous column tile (4 per column tile)
+    constexpr int GPK = 4 / KPQ;                  // accumulator groups finished per k tile: 2 or 1
+    constexpr bool COUNTED_OK = (KDIM == 512);    // the counted waits assume a pair of stores every second k tile
     constexpr int MAXN = 4096;
     __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + MAXN * 4];
     float* sbias = reinterpret_cast<float*>(sm + NST * STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1, kh = lane >> 5, l31 = lane & 31;
+    const int wr = (WCN == 2) ? wave >> 1 : wave, wc = (WCN == 2) ? wave & 1 : 0, kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y, s0 = blockIdx.x * 128;
     const int S = a.S, K = a.K, NT = a.N / 128;
     const bool interior = s0 + 128 <= S;
@@ -82,19 +94,20 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     }
 
     // ---- this lane's two token rows: scale, output address, activation fragments ----
-    float r0[2], mu[2] = {0.f, 0.f};        // row scale (rstd of the folded norm), row mean
-    char* orow[2];
-    bool ok[2];
-    u32x4_t afr[2][KS];
+    float r0[TMW], mu[TMW];                 // row scale (rstd of the folded norm), row mean
+    char* orow[TMW];
+    bool ok[TMW];
+    u32x4_t afr[TMW][KS];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int sr = s0 + wr * 64 + tm * 32 + l31;
+    for (int tm = 0; tm < TMW; ++tm) {
+        mu[tm] = 0.f;
+        const int sr = s0 + wr * (32 * TMW) + tm * 32 + l31;
         ok[tm] = sr < S;
         const int s = min(sr, S - 1);                       // rows past the utterance end are clamped, never stored
         const long m = (long)b * S + s;
         if constexpr (NORM) { mu[tm] = a.rowstat[2 * m]; r0[tm] = a.rowstat[2 * m + 1]; }
         else r0[tm] = a.rowstat ? a.rowstat[m] : 1.f;
-        orow[tm] = reinterpret_cast<char*>(a.out16) + (m * a.ldo + wc * 64) * 2 + kh * 16;
+        orow[tm] = reinterpret_cast<char*>(a.out16) + (m * a.ldo + wc * (32 * TNW)) * 2 + kh * 16;
         const unsigned short* arow = a.A16 + m * a.lda;
         // token shift: the first half of the features comes from the previous frame, zeros at frame 0
         const unsigned short* prow = (AMODE == A_SHIFT) ? (s > 0 ? arow - a.lda : reinterpret_cast<const unsigned short*>(a.zeros)) : arow;
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     }
     copy_piece(NST - 1, 0);
 
-    const int rowB = wc * 64 + l31;
+    const int rowB = wc * (32 * TNW) + l31;
     const char* fbase = sm + rowB * 128;
     auto read_b1 = [&](int slot, int sub, int tn, u32x4_t& dst) __attribute__((always_inline)) {
 #ifdef MSF2_DIAG_ASTAT_NOREAD
@@ -143,19 +156,21 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         const int row = rowB + tn * 32;
         dst = *reinterpret_cast<const u32x4_t*>(fbase + slot * STAGE + tn * 32 * 128 + (((2 * sub + kh) ^ bf_swz128(row)) << 4));
     };
-    auto read_b = [&](int slot, int sub, u32x4_t (&fb)[2]) __attribute__((always_inline)) {
+    auto read_b = [&](int slot, int sub, u32x4_t (&fb)[TNW]) __attribute__((always_inline)) {
 #ifdef MSF2_DIAG_ASTAT_NOREAD
         if (slot >= 0) return;         // timing-only build: no fragment reads
 #endif
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < TNW; ++tn) {
             const int row = rowB + tn * 32;
             fb[tn] = *reinterpret_cast<const u32x4_t*>(fbase + slot * STAGE + tn * 32 * 128 + (((2 * sub + kh) ^ bf_swz128(row)) << 4));
         }
     };
 
-    f32x16 acc[2][2][2];
-    bool st_ok[2] = {false, false};     // whether this lane stores its row of a finished tile (false while there is none)
+    f32x16 acc[2][TMW][TNW];
+    bool st_ok[TMW];                    // whether this lane stores its row of a finished tile (false while there is none)
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm) st_ok[tm] = false;
     u32x2_t pk[4];
     float4 bq[2][2];               // bias (c1) of the two accumulator groups finished per k tile: [k tile parity][group]
     float4 bq2[2][2];              // ACT_NORM: c2 of the same groups
@@ -163,17 +178,17 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
 
     // bias of groups g0, g0 + 1 of MFMA tile q of the column tile starting at nb (broadcast reads: two addresses per wave)
     auto load_bias = [&](float4 (&dst)[2], int q, int g0, int nb) __attribute__((always_inline)) {
-        const float* p = sbias + nb + wc * 64 + (q & 1) * 32 + 4 * kh;
+        const float* p = sbias + nb + wc * (32 * TNW) + (q % TNW) * 32 + 4 * kh;
         dst[0] = *reinterpret_cast<const float4*>(p + 8 * g0);
-        dst[1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
+        if (GPK == 2) dst[1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
     };
     // (both vectors of the folded norm; the plain epilogue has only the bias)
     auto load_vecs = [&](int par, int q, int g0, int nb) __attribute__((always_inline)) {
         load_bias(bq[par], q, g0, nb);
         if constexpr (NORM) {
-            const float* p = sbias + MAXN / 2 + nb + wc * 64 + (q & 1) * 32 + 4 * kh;
+            const float* p = sbias + MAXN / 2 + nb + wc * (32 * TNW) + (q % TNW) * 32 + 4 * kh;
             bq2[par][0] = *reinterpret_cast<const float4*>(p + 8 * g0);
-            bq2[par][1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
+            if (GPK == 2) bq2[par][1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
         }
     };
     // The arithmetic of one accumulator group (4 values of one row) takes the shadows of 8 MFMAs, one phase per MFMA, each
@@ -189,8 +204,10 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     auto epi_slot = [&](auto par_tag, int kt, int m) __attribute__((always_inline)) {
         constexpr int PP = decltype(par_tag)::value ^ 1;
         constexpr bool SIG = (ACT == 1 || ACT == 2);
-        const int q = kt >> 1, tm = q >> 1, tn = q & 1;
-        const int gi = m >> 3, g = (kt & 1) * 2 + gi, ph = m & 7;
+        // K = 512: two groups per k tile (slots 0-7, 8-15); K = 1024: one (slots 0-7; slots 8-15 stay empty)
+        const int q = kt / KPQ, tm = q / TNW, tn = q % TNW;
+        const int gi = m >> 3, g = (kt % KPQ) * GPK + gi, ph = m & 7;
+        if (gi >= GPK) return;
         if (ph == 0) {
             asm volatile("" : "+v"(r0[tm]));
 #pragma unroll
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     };
     // the four packed groups of MFMA tile q -> two 16-byte stores per lane (rows of 64 contiguous bytes per tile)
     auto store_tile = [&](int q, int nb) __attribute__((always_inline)) {
-        const int tm = q >> 1, tn = q & 1;
+        const int tm = q / TNW, tn = q % TNW;
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
             // lanes 0-31 end up with [own group k | upper half's group k], lanes 32-63 with [lower half's group k + 1 | own]
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     // slot, pieces 1 - 3 in the first three MFMA steps of the next k tile.
     // Order of the counted operations per k tile kt: [pieces 1 2 3 of stage kt + 3] [wait for stage kt + 1] [piece 0 of
     // stage kt + 4] [2 stores if kt is odd]: two stages and one pair of stores are younger than the awaited stage.
-    u32x4_t fb[2][2];              // weight fragments of two consecutive MFMA steps (ping-pong: step parity)
+    u32x4_t fb[2][TNW];            // weight fragments of two consecutive MFMA steps (ping-pong: step parity)
     auto column_tile = [&](auto par_tag, int ct, bool counted) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         const int nprev = (ct - 1) * 128;
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                 if (sub == 3) {
                     // the fragments of this step are in registers and the next stage has landed; then every wave is done
                     // reading this stage and it can be refilled
-                    if (counted) {
+                    if (COUNTED_OK && counted) {
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D + 2) : "memory");
                     } else {
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * D) : "memory");
@@ -299,17 +316,23 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (kt == 0 && sub == 0) {
-                        if (j < 2) mfma_astat_first<0>(acc[PAR][0][j & 1], fb[0][j & 1], afr[0][0]);
-                        else mfma_astat_first<1>(acc[PAR][1][j & 1], fb[0][j & 1], afr[1][0]);
+                    if constexpr (TMW == 2) {
+                        if (kt == 0 && sub == 0) {
+                            if (j < 2) mfma_astat_first<0>(acc[PAR][0][j & 1], fb[0][j & 1], afr[0][0]);
+                            else mfma_astat_first<1>(acc[PAR][TMW - 1][j & 1], fb[0][j & 1], afr[TMW - 1][0]);
+                        } else {
+                            if (j < 2) mfma_astat<0>(acc[PAR][0][j & 1], fb[sub & 1][j & 1], afr[0][kt * 4 + sub]);
+                            else mfma_astat<1>(acc[PAR][TMW - 1][j & 1], fb[sub & 1][j & 1], afr[TMW - 1][kt * 4 + sub]);
+                        }
                     } else {
-                        if (j < 2) mfma_astat<0>(acc[PAR][0][j & 1], fb[sub & 1][j & 1], afr[0][kt * 4 + sub]);
-                        else mfma_astat<1>(acc[PAR][1][j & 1], fb[sub & 1][j & 1], afr[1][kt * 4 + sub]);
+                        if (kt == 0 && sub == 0) mfma_astat_first<0>(acc[PAR][0][j % TNW], fb[0][j % TNW], afr[0][0]);
+                        else mfma_astat<0>(acc[PAR][0][j % TNW], fb[sub & 1][j % TNW], afr[0][kt * 4 + sub]);
                     }
-                    if (j < 2) {
+                    if (j < TNW) {
                         if (sub < 3) read_b1(kt & 3, sub + 1, j, fb[(sub + 1) & 1][j]);
                         else read_b1((kt + 1) & 3, 0, j, fb[0][j]);
-                    } else if (j == 2) {
+                    }
+                    if (j == 2) {
 #ifndef MSF2_DIAG_ASTAT_NOCOPY
                         if (sub < 3) copy_piece((kt + 3) & 3, sub + 1);     // (the stage whose piece 0 went out in the k tile before)
                         else copy_piece(kt & 3, 0);                         // stream tile + 4 goes into the slot just released
@@ -318,9 +341,9 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                             if (kt == KT - NST) wnext = wrap_prev ? reinterpret_cast<const unsigned short*>(a.W) : wnext + tile_step;
                             else wnext += 64;
                         }
-                    } else if (sub == 3) {
-                        // bias of the two groups the NEXT k tile finishes (the next column tile's first, after the last k tile)
-                        if (kt < KT - 1) load_vecs((kt + 1) & 1, (kt + 1) >> 1, ((kt + 1) & 1) * 2, nprev);
+                    } else if (j == 3 && sub == 3) {
+                        // bias of the group(s) the NEXT k tile finishes (the next column tile's first, after the last k tile)
+                        if (kt < KT - 1) load_vecs((kt + 1) & 1, (kt + 1) / KPQ, ((kt + 1) % KPQ) * GPK, nprev);
                         else load_vecs(0, 0, 0, nprev + 128);
                     }
 #ifndef MSF2_DIAG_ASTAT_NOEPI
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                 }
             }
 #if !defined(MSF2_DIAG_ASTAT_NOEPI) && !defined(MSF2_DIAG_ASTAT_NOSTORE)
-            if (kt & 1) store_tile(kt >> 1, nprev);
+            if (kt % KPQ == KPQ - 1) store_tile(kt / KPQ, nprev);
 #endif
         }
     };
@@ -341,16 +364,17 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     read_b(0, 0, fb[0]);
     load_vecs(0, 0, 0, 0);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][tm][tn][r] = 0.f;
     typedef std::integral_constant<int, 0> P0;
     typedef std::integral_constant<int, 1> P1;
     for (int ct = 0; ct < NT; ct += 2) {
         column_tile(P0(), ct, interior && ct >= 2);
-        st_ok[0] = ok[0]; st_ok[1] = ok[1];               // from the second column tile on there is a finished tile to store
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm) st_ok[tm] = ok[tm];     // from the second column tile on there is a finished tile to store
         if (ct + 1 < NT) column_tile(P1(), ct + 1, interior && ct + 1 >= 2);
     }
     // the last column tile is finished with nothing to hide behind (same slots, no MFMAs between them)
@@ -358,18 +382,18 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     if (NT & 1) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            load_vecs(kt & 1, kt >> 1, (kt & 1) * 2, nlast);
+            load_vecs(kt & 1, kt / KPQ, (kt % KPQ) * GPK, nlast);
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P1(), kt, m);    // (the tag names the set that would FOLLOW: the slot reads set 0)
-            if (kt & 1) store_tile(kt >> 1, nlast);
+            if (kt % KPQ == KPQ - 1) store_tile(kt / KPQ, nlast);
         }
     } else {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            load_vecs(kt & 1, kt >> 1, (kt & 1) * 2, nlast);
+            load_vecs(kt & 1, kt / KPQ, (kt % KPQ) * GPK, nlast);
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P0(), kt, m);
-            if (kt & 1) store_tile(kt >> 1, nlast);
+            if (kt % KPQ == KPQ - 1) store_tile(kt / KPQ, nlast);
         }
     }
     // the wrapped-around stages are still landing in this workgroup's LDS: they must have, before it is given away
