@@ -113,9 +113,18 @@ __global__ void rowsq_finalize_kernel(const float* __restrict__ part, int np, fl
     if (m >= M) return;
     float ss = 0.f;
     const int h = shift ? np / 2 : 0;
-    for (int p = h; p < np; ++p) ss += part[m * np + p];
-    if (shift && m % S != 0)
-        for (int p = 0; p < h; ++p) ss += part[(m - 1) * np + p];
+    if ((np & 7) == 0) {           // 16-byte loads, summed in the same order as the scalar loop
+        const float4* own = reinterpret_cast<const float4*>(part + m * np);
+        for (int p = h / 4; p < np / 4; ++p) { const float4 v = own[p]; ss += v.x; ss += v.y; ss += v.z; ss += v.w; }
+        if (shift && m % S != 0) {
+            const float4* prev = reinterpret_cast<const float4*>(part + (m - 1) * np);
+            for (int p = 0; p < h / 4; ++p) { const float4 v = prev[p]; ss += v.x; ss += v.y; ss += v.z; ss += v.w; }
+        }
+    } else {
+        for (int p = h; p < np; ++p) ss += part[m * np + p];
+        if (shift && m % S != 0)
+            for (int p = 0; p < h; ++p) ss += part[(m - 1) * np + p];
+    }
     out[m] = 1.0f / fmaxf(sqrtf(ss) * rsqrtf((float)C), 1e-5f);
 }
 
