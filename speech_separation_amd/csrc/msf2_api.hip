@@ -366,7 +366,7 @@ static void run_attention(const Ctx& c, const AttnWs& w, const float* hu, int ld
     // hu16 (bf16 mode): the hidden tensor [v | u | qk] is read as bf16 from there instead of fp32 from hu
     const long M = c.M;
     if (hu16)
-        hipLaunchKernelGGL(qk_prep_bf16_kernel, dim3(cdiv(M, 8)), dim3(256), 0, c.st, hu16 + 2 * E, ldhu, gamma, beta, freqs, w.q4, M, c.S);
+        hipLaunchKernelGGL(qk_prep_bf16_kernel, dim3(cdiv(M, 32)), dim3(256), 0, c.st, hu16 + 2 * E, ldhu, gamma, beta, freqs, w.q4, M, c.S);
     else
         hipLaunchKernelGGL(qk_prep_kernel<false>, dim3(cdiv(M, 4)), dim3(256), 0, c.st, (const void*)(hu + 2 * E), ldhu, gamma, beta, freqs, w.q4, M, c.S);
     const float* hsrc = hu16 ? reinterpret_cast<const float*>(hu16) : hu;

@@ -421,29 +421,47 @@ __global__ __launch_bounds__(256) void qk_prep_bf16_kernel(const unsigned short*
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ freqs, float* __restrict__ q4,
                                                            long M, int S) {
+    // a thread handles its 4 columns of QP_ROWS rows, 8 rows apart: all row loads first, the per-head gains once
+    constexpr int QP_ROWS = 4;
     const int p = threadIdx.x & 31;
-    const long m = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (m >= M) return;
-    const float4 x = bf16x4_ld(qk + m * ld + 4 * p);
-    float c0 = 1.f, s0 = 0.f, c1 = 1.f, s1 = 0.f;
-    if (p < 8) {
-        const float pos = (float)(m % S);
-        const float a0 = pos * freqs[2 * p], a1 = pos * freqs[2 * p + 1];
-        c0 = __cosf(a0); s0 = __sinf(a0);
-        c1 = __cosf(a1); s1 = __sinf(a1);
+    const long mb = (long)blockIdx.x * (8 * QP_ROWS) + (threadIdx.x >> 5);
+    float4 xs[QP_ROWS];
+#pragma unroll
+    for (int r = 0; r < QP_ROWS; ++r) {
+        const long m = mb + 8 * r;
+        xs[r] = bf16x4_ld(qk + (m < M ? m : M - 1) * ld + 4 * p);
     }
+    float4 gs[4], bs[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + h * MSF2_QK_DIM + 4 * p);
-        const float4 bb = *reinterpret_cast<const float4*>(beta + h * MSF2_QK_DIM + 4 * p);
-        const float y0 = x.x * g.x + bb.x, y1 = x.y * g.y + bb.y, y2 = x.z * g.z + bb.z, y3 = x.w * g.w + bb.w;
-        float o0 = y0 * c0 - y1 * s0, o1 = y1 * c0 + y0 * s0;
-        float o2 = y2 * c1 - y3 * s1, o3 = y3 * c1 + y2 * s1;
-        if (h == 0) { o0 *= (1.0f / MSF2_GROUP); o1 *= (1.0f / MSF2_GROUP); o2 *= (1.0f / MSF2_GROUP); o3 *= (1.0f / MSF2_GROUP); }
-        uint2 v;
-        v.x = pk_bf16_pair(o0, o1);
-        v.y = pk_bf16_pair(o2, o3);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(q4 + (long)h * M * MSF2_QK_DIM) + m * MSF2_QK_DIM + 4 * p) = v;
+        gs[h] = *reinterpret_cast<const float4*>(gamma + h * MSF2_QK_DIM + 4 * p);
+        bs[h] = *reinterpret_cast<const float4*>(beta + h * MSF2_QK_DIM + 4 * p);
+    }
+    const float f0 = (p < 8) ? freqs[2 * p] : 0.f, f1 = (p < 8) ? freqs[2 * p + 1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < QP_ROWS; ++r) {
+        const long m = mb + 8 * r;
+        if (m >= M) break;
+        const float4 x = xs[r];
+        float c0 = 1.f, s0 = 0.f, c1 = 1.f, s1 = 0.f;
+        if (p < 8) {
+            const float pos = (float)(m % S);
+            const float a0 = pos * f0, a1 = pos * f1;
+            c0 = __cosf(a0); s0 = __sinf(a0);
+            c1 = __cosf(a1); s1 = __sinf(a1);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float4 g = gs[h], bb = bs[h];
+            const float y0 = x.x * g.x + bb.x, y1 = x.y * g.y + bb.y, y2 = x.z * g.z + bb.z, y3 = x.w * g.w + bb.w;
+            float o0 = y0 * c0 - y1 * s0, o1 = y1 * c0 + y0 * s0;
+            float o2 = y2 * c1 - y3 * s1, o3 = y3 * c1 + y2 * s1;
+            if (h == 0) { o0 *= (1.0f / MSF2_GROUP); o1 *= (1.0f / MSF2_GROUP); o2 *= (1.0f / MSF2_GROUP); o3 *= (1.0f / MSF2_GROUP); }
+            uint2 v;
+            v.x = pk_bf16_pair(o0, o1);
+            v.y = pk_bf16_pair(o2, o3);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(q4 + (long)h * M * MSF2_QK_DIM) + m * MSF2_QK_DIM + 4 * p) = v;
+        }
     }
 }
 
