@@ -88,6 +88,7 @@ struct Knobs {
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
     bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
+    bool astat_merge = true;    // "astat_merge": gate and proj_in of the gated TCN block in one walk of the register-resident-activation kernel
     bool astat_k1024 = true;    // "astat_k1024": the K = 1024 projection (to_out) on the register-resident-activation kernel
     bool linkv_dma = true;      // "linkv_dma": bf16 key/value summary on the global -> LDS kernel with transposing reads (0: register-staged tile kernel)
     int stage_a_split_below = -1;  // "stage_a_split_below": TCN stage A runs its quarter-frames form below this many blocks (-1: default rule)
@@ -474,16 +475,26 @@ static int launch_stage_a_bf16(const Ctx& c, const TcnWs& w, const unsigned shor
 // sq_part: optional [M][..] partial row sums of squares of the block's result (see launch_proj); returns their slab width
 static int run_gated_tcn_bf16(const Ctx& c, const TcnWs& w, float* x, unsigned short* x16, const msf2_layer_weights& lw, int C, bool have_ln,
                               float* sq_part) {
-    {
-        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);      // the gate exists as bf16 only
-        a.bias = lw.b_gg; a.act = 2; a.A16 = x16; a.out16 = w.g16;
-        launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
-    }
     if (!have_ln) launch_rowstat<1>(c, x, C, w.rowstat, C, 0, 1e-5f);
-    {
-        ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, nullptr, C);
-        a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a; a.A16 = x16;
-        launch_proj<A_PLAIN, EPI_NORM>(c, a);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (c.k.astat && c.k.astat_merge && x16 && C == 512 && (long)cdiv(c.S, 128) * c.B >= c.cus && al16(x16) && al16(w.g16) && al16(w.h16a) &&
+        al16(lw.w_gg) && al16(lw.w_in)) {
+        // the gate and proj_in read the same rows: one walk of the register-resident-activation kernel over both weight matrices
+        ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);
+        a.W2 = lw.w_in; a.bias = lw.b_gg; a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.A16 = x16;
+        a.out16 = w.g16; a.out16b = w.h16a;
+        hipLaunchKernelGGL((proj_astat_bf16_kernel<A_PLAIN, ACT_GATE_NORM>), dim3(cdiv(c.S, 128), c.B), dim3(256), 0, c.st, a);
+    } else {
+        {
+            ProjArgs a = proj_args(x, C, lw.w_gg, C, C, c.S, nullptr, C);      // the gate exists as bf16 only
+            a.bias = lw.b_gg; a.act = 2; a.A16 = x16; a.out16 = w.g16;
+            launch_proj<A_PLAIN, EPI_RS_BIAS_ACT>(c, a);
+        }
+        {
+            ProjArgs a = proj_args(x, C, lw.w_in, C, C, c.S, nullptr, C);
+            a.rowstat = w.rowstat; a.c1 = lw.c1_in; a.c2 = lw.c2_in; a.out16 = w.h16a; a.A16 = x16;
+            launch_proj<A_PLAIN, EPI_NORM>(c, a);
+        }
     }
     unsigned short* h16 = w.h16a;
     unsigned short* hn16 = w.h16b;
@@ -805,6 +816,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
+    else if (!strcmp(name, "astat_merge")) k.astat_merge = atoi(value) != 0;
     else if (!strcmp(name, "astat_k1024")) k.astat_k1024 = atoi(value) != 0;
     else if (!strcmp(name, "linkv_dma")) k.linkv_dma = atoi(value) != 0;
     else if (!strcmp(name, "stage_a_split_below")) k.stage_a_split_below = atoi(value);

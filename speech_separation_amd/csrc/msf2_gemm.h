@@ -361,6 +361,7 @@ struct ProjArgs {
     // EPI_TCN / EPI_TCN_G, small-grid tile forms only (init_tile): the utterance statistics as stage A left them, [B][stat_nblk][2]
     // partial (sum, sum of squares); the kernel reduces them itself (bstat and c1f null) in the order stats_finalize_kernel does.
     const float* stat_part;  int stat_nblk;  float stat_eps;  double stat_count;
+    unsigned short* out16b;        // register-resident kernel walking two projections of the same rows: bf16 output of the second (W2, c1, c2, rowstat)
 };
 
 template <int AMODE, int EPI>

@@ -55,6 +55,12 @@ template <int TM> __device__ __forceinline__ void mfma_astat_first(f32x16& c, co
 #endif
 
 constexpr int ACT_NORM = 16;      // epilogue kind: per-row (mean, rstd) from a.rowstat, per-column c1 / c2, no activation
+// Two projections of the same rows in one walk (the gate and proj_in of the gated TCN block, mossformer2_block.py:556-566):
+// column tiles 0 .. N/128 - 1 are sigmoid(A W^T + bias) -> out16, tiles N/128 .. 2 N/128 - 1 the folded LayerNorm of
+// A W2^T -> out16b.  The activation rows are loaded once for both.  Arithmetic: the folded-norm form for every tile
+// (rstd' (acc - mean c2') + c1' with c2' = 0, c1' = bias, rstd' = 1 on the gate tiles: the same roundings as r0 acc + bias
+// with r0 = 1), the sigmoid phases under a wave-uniform branch on the gate tiles only.
+constexpr int ACT_GATE_NORM = 32;
 
 // KDIM = 512: 2 x 2 waves, a wave holds 64 rows x 512 k (two row tiles) and finishes 64 of a column tile's 128 outputs.
 // KDIM = 1024: 4 x 1 waves, a wave holds 32 rows x 1024 k (one row tile) and finishes all 128 outputs of the column tile
@@ -64,7 +70,8 @@ template <int AMODE, int ACT, int KDIM = 512>
 __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs a) {
     static_assert(KDIM == 512 || KDIM == 1024, "a wave holds 256 registers of activation fragments");
     static_assert(KDIM == 512 || AMODE == A_PLAIN, "the token shift is built for K = 512");
-    constexpr bool NORM = (ACT == ACT_NORM);
+    constexpr bool MERGED = (ACT == ACT_GATE_NORM);
+    constexpr bool NORM = (ACT == ACT_NORM) || MERGED;
     constexpr int NST = 4, STAGE = 128 * 128;     // ring: 4 stages of 128 weight rows x 128 B (k tile of 64)
     constexpr int D = 4;                          // copies per wave and stage (16 of 1 KiB per stage)
     constexpr int KT = KDIM / 64, KS = KDIM / 16; // k tiles and MFMA steps (k 16)
@@ -80,12 +87,17 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = (WCN == 2) ? wave >> 1 : wave, wc = (WCN == 2) ? wave & 1 : 0, kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y, s0 = blockIdx.x * 128;
-    const int S = a.S, K = a.K, NT = a.N / 128;
+    const int S = a.S, K = a.K, NT = MERGED ? 2 * (a.N / 128) : a.N / 128, NT1 = a.N / 128;
     const bool interior = s0 + 128 <= S;
 
     // ---- bias vector -> LDS (read by the epilogue arithmetic as broadcast 16-byte reads) ----
     for (int i = tid; i < a.N / 4; i += 256) {
-        if constexpr (NORM) {
+        if constexpr (MERGED) {       // gate columns: c1' = bias, c2' = 0; proj_in columns behind them
+            reinterpret_cast<float4*>(sbias)[i] = a.bias ? ld4(a.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(sbias + MAXN / 2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(sbias + a.N)[i] = ld4(a.c1 + 4 * i);
+            reinterpret_cast<float4*>(sbias + MAXN / 2 + a.N)[i] = ld4(a.c2 + 4 * i);
+        } else if constexpr (NORM) {
             reinterpret_cast<float4*>(sbias)[i] = ld4(a.c1 + 4 * i);
             reinterpret_cast<float4*>(sbias + MAXN / 2)[i] = ld4(a.c2 + 4 * i);
         } else {
@@ -201,9 +213,12 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     // the MFMA statements, and the arithmetic hangs on their operands (the optimiser otherwise gathers all of a k tile's
     // arithmetic behind its last MFMA, where nothing hides it).
     float ex[4] = {0.f, 0.f, 0.f, 0.f};
+    bool gate_prev = true;         // MERGED: whether the tile being finished is a gate tile (wave-uniform)
+    // MERGED: from a row of the first output to the same row of the second, less the second's column offset in the walk (wave-uniform)
+    const long out_delta = MERGED ? (reinterpret_cast<char*>(a.out16b) - reinterpret_cast<char*>(a.out16)) - (long)a.N * 2 : 0;
     auto epi_slot = [&](auto par_tag, int kt, int m) __attribute__((always_inline)) {
         constexpr int PP = decltype(par_tag)::value ^ 1;
-        constexpr bool SIG = (ACT == 1 || ACT == 2);
+        constexpr bool SIG = (ACT == 1 || ACT == 2 || MERGED);
         // K = 512: two groups per k tile (slots 0-7, 8-15); K = 1024: one (slots 0-7; slots 8-15 stay empty)
         const int q = kt / KPQ, tm = q / TNW, tn = q % TNW;
         const int gi = m >> 3, g = (kt % KPQ) * GPK + gi, ph = m & 7;
@@ -219,8 +234,9 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         } else if (ph == 1) {
             if constexpr (NORM) {
                 asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+                const float rs = (MERGED && gate_prev) ? 1.f : r0[tm];      // (gate tiles: no row scale)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = r0[tm] * val[e] + f4get(bq[kt & 1][gi], e);
+                for (int e = 0; e < 4; ++e) val[e] = rs * val[e] + f4get(bq[kt & 1][gi], e);
                 asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
             }
             if constexpr (SIG) {
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                 asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
             }
         } else if (ph == 2 || ph == 3) {
-            if constexpr (SIG) {
+            if (SIG && (!MERGED || gate_prev)) {
                 const int e0 = (ph - 2) * 2;
                 asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
                 ex[e0] = __builtin_amdgcn_exp2f(ex[e0]);
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                 asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
             }
         } else if (ph == 5 || ph == 6) {
-            if constexpr (SIG) {
+            if (SIG && (!MERGED || gate_prev)) {
                 const int e0 = (ph - 5) * 2;
                 asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
                 ex[e0] = __builtin_amdgcn_rcpf(ex[e0]);
@@ -258,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
             for (int e = 0; e < 4; ++e) {
                 if constexpr (ACT == 1) val[e] = val[e] * ex[e];
                 else if constexpr (ACT == 2) val[e] = ex[e];
+                else if constexpr (MERGED) val[e] = gate_prev ? ex[e] : val[e];
             }
             pk[g].x = pk_bf16_2(val[0], val[1]);
             pk[g].y = pk_bf16_2(val[2], val[3]);
@@ -273,7 +290,9 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
             const auto rx = __builtin_amdgcn_permlane32_swap(pk[k].x, pk[k + 1].x, false, false);
             const auto ry = __builtin_amdgcn_permlane32_swap(pk[k].y, pk[k + 1].y, false, false);
             const uint4 o = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-            if (st_ok[tm]) *reinterpret_cast<uint4*>(orow[tm] + (nb + tn * 32) * 2 + 16 * k) = o;
+            char* ob = orow[tm];
+            if constexpr (MERGED) ob += gate_prev ? 0 : out_delta;
+            if (st_ok[tm]) *reinterpret_cast<uint4*>(ob + (nb + tn * 32) * 2 + 16 * k) = o;
         }
     };
 
@@ -294,6 +313,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         // (the source pointer moves on after piece 3 of a stage; the stage in flight when k tile 4 starts is the last k tile
         // of this column tile, so the pointer then steps to the next column tile -- or wraps)
         const bool wrap_prev = ct == NT - 1;
+        if constexpr (MERGED) gate_prev = ct - 1 < NT1;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -338,7 +358,11 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                         else copy_piece(kt & 3, 0);                         // stream tile + 4 goes into the slot just released
 #endif
                         if (sub == 2) {
-                            if (kt == KT - NST) wnext = wrap_prev ? reinterpret_cast<const unsigned short*>(a.W) : wnext + tile_step;
+                            if (kt == KT - NST) {
+                                if (wrap_prev) wnext = reinterpret_cast<const unsigned short*>(a.W);
+                                else if (MERGED && ct == NT1 - 1) wnext = reinterpret_cast<const unsigned short*>(a.W2);     // the second projection's weights
+                                else wnext += tile_step;
+                            }
                             else wnext += 64;
                         }
                     } else if (j == 3 && sub == 3) {
@@ -379,6 +403,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     }
     // the last column tile is finished with nothing to hide behind (same slots, no MFMAs between them)
     const int nlast = (NT - 1) * 128;
+    if constexpr (MERGED) gate_prev = false;
     if (NT & 1) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
