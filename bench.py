@@ -177,17 +177,23 @@ def roofline_record(model, prec_name, which, ms, flops, nl, B, T, traffic):
     # bf16: neither roof binds -- the kernels are paced by the L2 -> LDS operand copies (see the copy-only bound); the record
     # carries the fraction of both roofs, `frac` is the MFMA one (the larger).  Algorithmic bytes: bf16 images of the
     # operands read once and the result written once.
+    import torch
+    resident = which == 0 and C == 512 and -(-model.cfg.frames(T) // 128) * B >= torch.cuda.get_device_properties(0).multi_processor_count
     if which == 0:
-        name = "gemm_kernel_bf16_dma<ProjNT<0,5>> (TCN pointwise, two products, bf16 MFMA 32x32x16)"
+        # with a 128-row workgroup per CU or more, 7 of a layer's 8 launches are the register-resident form (the gated last block
+        # stays on the tile kernel); the timer averages over all 8
+        name = ("proj_astat_bf16_kernel<0,64> (TCN pointwise, two products; 32 rows of h and of t resident in registers per wave, weights "
+                "streamed; bf16 MFMA 32x32x16) x7 + gemm_kernel_bf16_dma<ProjNT<0,6>> x1 per layer" if resident else
+                "gemm_kernel_bf16_dma<ProjNT<0,5>> (TCN pointwise, two products, bf16 MFMA 32x32x16)")
         gbytes = 3.0 * M * C * 2 / 1e9                                    # h, t in; h' out
-        copy_ms = BF16_TCN_COPY_ONLY_MS_AT_255936_ROWS * M / 255936.0
+        copy_ms = None if resident else BF16_TCN_COPY_ONLY_MS_AT_255936_ROWS * M / 255936.0
     else:
         name = ("proj_astat_bf16_kernel<1,1> (token-shifted to_hidden|to_qk projection N=2176, activation rows resident in "
                 "registers, bf16 MFMA 32x32x16)")
         gbytes = (M * C + M * (4 * C + 128)) * 2 / 1e9                    # x in; [v|u|qk] out
         copy_ms = None
     hbm = gbytes / (ms * 1e-3)
-    binding = ("l2->lds operand copy path (neither roof)" if which == 0 else
+    binding = ("l2->lds operand copy path (neither roof)" if which == 0 and not resident else
                "in-order issue of one wave per SIMD: fragment reads, weight copies and epilogue arithmetic add to the MFMA time (neither roof)")
     return {"bound": "mfma", "binding_resource": binding, "kernel": name,
             "achieved": tf, "peak": PEAK_BF16_MFMA, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA,

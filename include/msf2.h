@@ -200,7 +200,7 @@ int msf2_timing_begin_kernel(int which);
  * number of tiles of the call).  name: "ncol_loop", "big_maxn", "no_big", "geom2", "narrow", "narrow_below", "many_min",
  * "row128", "own_stats", "attn_fused", "attn_fused_min", "astat" (0: the bf16 K = 512 projections with a bias / activation
  * epilogue stay on the tile kernels instead of the register-resident-activation kernel), "astat_k1024" (0: the K = 1024 one too), "astat_merge" (0: gate and proj_in of the
- * gated TCN block as two walks of that kernel instead of one), "store_aware", "linkv_dma" (0: the bf16
+ * gated TCN block as two walks of that kernel instead of one), "astat_tcn" (0: the two-product TCN contraction on the tile kernel), "store_aware", "linkv_dma" (0: the bf16
  * key/value summary on the register-staged tile kernel), "stage_a_split_below" (integers as text) or "geom3", "geom4" (letters naming
  * projections).  name == NULL restores the defaults; an unknown name returns -1.  The library reads no environment
  * variable. */

@@ -88,6 +88,7 @@ struct Knobs {
     int narrow_below = -1;      // "narrow_below": the small-grid forms are taken below this many 128 x 128 tiles (-1: two per CU fp32, one per CU + 1 bf16)
     bool astat = true;          // "astat": bf16 K = 512 projections with bias / activation epilogue on the register-resident-activation kernel
     bool store_aware = true;    // "store_aware": a workgroup that walks several tiles lets an epilogue's stores drain under the next K steps
+    bool astat_tcn = true;      // "astat_tcn": the two-product TCN contraction on the register-resident-activation kernel
     bool astat_merge = true;    // "astat_merge": gate and proj_in of the gated TCN block in one walk of the register-resident-activation kernel
     bool astat_k1024 = true;    // "astat_k1024": the K = 1024 projection (to_out) on the register-resident-activation kernel
     bool linkv_dma = true;      // "linkv_dma": bf16 key/value summary on the global -> LDS kernel with transposing reads (0: register-staged tile kernel)
@@ -258,6 +259,16 @@ static int launch_proj(const Ctx& c, const ProjArgs& a) {
             }
         }
         if (a.stat_part) { g_bad_operand = true; return 0; }      // only the small-grid forms reduce the statistics themselves
+        if constexpr (EPI == EPI_TCN) {
+            // the two-product contraction with h and t resident in registers (32 rows of each per wave), weights streamed
+            const long wgs = (long)cdiv(c.S, 128) * c.B;
+            if (c.k.astat && c.k.astat_tcn && a.K == 512 && a.N == 512 && a.res16 == a.A16 && a.ldr == a.lda && a.c1f && a.bstat && a.out16 &&
+                (a.lda & 7) == 0 && (a.ldo & 7) == 0 && al16(a.A16) && al16(a.A2_16) && al16(a.out16) && al16(a.W) && al16(a.W2) &&
+                al16(a.c1f) && wgs >= c.cus) {
+                hipLaunchKernelGGL((proj_astat_bf16_kernel<A_PLAIN, ACT_TCN>), dim3(cdiv(c.S, 128), c.B), dim3(256), 0, c.st, al);
+                return 0;
+            }
+        }
         if constexpr (!P::PAIRED) {
             // Whole-line row pieces, one column tile per workgroup: measured at 64 / 16 / 4 x 4 s, the two-product contraction
             // 6-9 % faster than the stream form (fabric reads 1.33 -> 0.84 GB per launch: the column tiles of a row tile
@@ -760,7 +771,7 @@ const char* msf2_strerror(int code) {
     }
 }
 int msf2_last_hip_error(void) { return g_last_hip_error; }
-int msf2_version(void) { return 4; }
+int msf2_version(void) { return 5; }
 int msf2_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(msf2_config);
@@ -816,6 +827,7 @@ int msf2_debug_kernel_choice(const char* name, const char* value) {
     else if (!strcmp(name, "row128")) k.row128 = atoi(value);
     else if (!strcmp(name, "many_min")) k.many_min = atoi(value);
     else if (!strcmp(name, "narrow_below")) k.narrow_below = atoi(value);
+    else if (!strcmp(name, "astat_tcn")) k.astat_tcn = atoi(value) != 0;
     else if (!strcmp(name, "astat_merge")) k.astat_merge = atoi(value) != 0;
     else if (!strcmp(name, "astat_k1024")) k.astat_k1024 = atoi(value) != 0;
     else if (!strcmp(name, "linkv_dma")) k.linkv_dma = atoi(value) != 0;

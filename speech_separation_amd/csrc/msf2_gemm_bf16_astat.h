@@ -61,6 +61,14 @@ constexpr int ACT_NORM = 16;      // epilogue kind: per-row (mean, rstd) from a.
 // (rstd' (acc - mean c2') + c1' with c2' = 0, c1' = bias, rstd' = 1 on the gate tiles: the same roundings as r0 acc + bias
 // with r0 = 1), the sigmoid phases under a wave-uniform branch on the gate tiles only.
 constexpr int ACT_GATE_NORM = 32;
+// The two-product contraction of a TCN block (TCNBlock.forward, mossformer2_block.py:508-531, with the gate of this code's fused
+// form):   out16[m, n] = h[m, n] + sigmoid(sum_k h[m, k] Wg[n, k] + bias[n]) * (rstd_b * sum_k t[m, k] Wo[n, k] + c1f[b, n])
+// (A16 = h, A2_16 = t, W = Wg, W2 = Wo, c1f = the GroupNorm of t folded into a per-utterance column vector, bstat = (mean, rstd) of
+// the utterance).  4 x 1 waves; a wave holds 32 rows of h AND of t (128 + 128 registers); a column tile is 64 outputs: per MFMA step
+// two gate tiles (h fragment) and two product tiles (t fragment), a weight stage = 64 rows of Wg then 64 rows of Wo.  The residual
+// h[m, n] is taken from the resident h fragments (accumulator-file reads and two v_permlane32_swap per 16 columns): no memory
+// operation.  Same arithmetic per output as the tile kernel's epilogue.
+constexpr int ACT_TCN = 64;
 
 // KDIM = 512: 2 x 2 waves, a wave holds 64 rows x 512 k (two row tiles) and finishes 64 of a column tile's 128 outputs.
 // KDIM = 1024: 4 x 1 waves, a wave holds 32 rows x 1024 k (one row tile) and finishes all 128 outputs of the column tile
@@ -71,28 +79,36 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     static_assert(KDIM == 512 || KDIM == 1024, "a wave holds 256 registers of activation fragments");
     static_assert(KDIM == 512 || AMODE == A_PLAIN, "the token shift is built for K = 512");
     constexpr bool MERGED = (ACT == ACT_GATE_NORM);
+    constexpr bool TCN = (ACT == ACT_TCN);
+    static_assert(!TCN || (KDIM == 512 && AMODE == A_PLAIN), "two products of K = 512");
     constexpr bool NORM = (ACT == ACT_NORM) || MERGED;
+    constexpr int CW = TCN ? 64 : 128;            // output columns per column tile
     constexpr int NST = 4, STAGE = 128 * 128;     // ring: 4 stages of 128 weight rows x 128 B (k tile of 64)
     constexpr int D = 4;                          // copies per wave and stage (16 of 1 KiB per stage)
-    constexpr int KT = KDIM / 64, KS = KDIM / 16; // k tiles and MFMA steps (k 16)
-    constexpr int TMW = (KDIM == 512) ? 2 : 1;    // row tiles (32 rows) per wave
+    constexpr int KT = KDIM / 64;                 // k tiles per column tile
+    constexpr int KS = TCN ? 64 : KDIM / 16;      // resident fragments per row tile (TCN: 32 of h, then 32 of t)
+    constexpr int TMW = (KDIM == 512 && !TCN) ? 2 : 1;    // row tiles (32 rows) per wave
     constexpr int TNW = 4 / TMW;                  // MFMA column tiles (32 columns) per wave and column tile
     constexpr int WCN = TMW;                      // waves side by side: 2 (K = 512) or 1
-    constexpr int KPQ = KT / 4;                   // k tiles per finished MFMA tile of the previous column tile (4 per column tile)
+    constexpr int NFT = TCN ? 2 : 4;              // finished 32-column tiles per wave and column tile
+    constexpr int KPQ = KT / NFT;                 // k tiles per finished tile of the previous column tile
     constexpr int GPK = 4 / KPQ;                  // accumulator groups finished per k tile: 2 or 1
-    constexpr bool COUNTED_OK = (KDIM == 512);    // the counted waits assume a pair of stores every second k tile
+    constexpr bool COUNTED_OK = (KDIM == 512 && !TCN);    // the counted waits assume a pair of stores every second k tile
     constexpr int MAXN = 4096;
     __shared__ __attribute__((aligned(1024))) char sm[NST * STAGE + MAXN * 4];
     float* sbias = reinterpret_cast<float*>(sm + NST * STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = (WCN == 2) ? wave >> 1 : wave, wc = (WCN == 2) ? wave & 1 : 0, kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y, s0 = blockIdx.x * 128;
-    const int S = a.S, K = a.K, NT = MERGED ? 2 * (a.N / 128) : a.N / 128, NT1 = a.N / 128;
+    const int S = a.S, K = a.K, NT = MERGED ? 2 * (a.N / CW) : a.N / CW, NT1 = a.N / CW;
     const bool interior = s0 + 128 <= S;
 
     // ---- bias vector -> LDS (read by the epilogue arithmetic as broadcast 16-byte reads) ----
     for (int i = tid; i < a.N / 4; i += 256) {
-        if constexpr (MERGED) {       // gate columns: c1' = bias, c2' = 0; proj_in columns behind them
+        if constexpr (TCN) {          // gate bias; the folded GroupNorm vector of this workgroup's utterance
+            reinterpret_cast<float4*>(sbias)[i] = a.bias ? ld4(a.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            reinterpret_cast<float4*>(sbias + MAXN / 2)[i] = ld4(a.c1f + (long)b * a.N + 4 * i);
+        } else if constexpr (MERGED) {       // gate columns: c1' = bias, c2' = 0; proj_in columns behind them
             reinterpret_cast<float4*>(sbias)[i] = a.bias ? ld4(a.bias + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
             reinterpret_cast<float4*>(sbias + MAXN / 2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             reinterpret_cast<float4*>(sbias + a.N)[i] = ld4(a.c1 + 4 * i);
@@ -118,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         const int s = min(sr, S - 1);                       // rows past the utterance end are clamped, never stored
         const long m = (long)b * S + s;
         if constexpr (NORM) { mu[tm] = a.rowstat[2 * m]; r0[tm] = a.rowstat[2 * m + 1]; }
+        else if constexpr (TCN) r0[tm] = a.bstat[2 * b + 1];          // rstd of the utterance (the mean is folded into c1f)
         else r0[tm] = a.rowstat ? a.rowstat[m] : 1.f;
         orow[tm] = reinterpret_cast<char*>(a.out16) + (m * a.ldo + wc * (32 * TNW)) * 2 + kh * 16;
         const unsigned short* arow = a.A16 + m * a.lda;
@@ -125,12 +142,36 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         const unsigned short* prow = (AMODE == A_SHIFT) ? (s > 0 ? arow - a.lda : reinterpret_cast<const unsigned short*>(a.zeros)) : arow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int k = (2 * ks + kh) * 8;
-            const bool shifted = (AMODE == A_SHIFT) && (ks < KS / 2);
-            const unsigned short* src = shifted ? (s > 0 ? prow + k : prow + (k & 63)) : arow + k;
-            afr[tm][ks] = *reinterpret_cast<const u32x4_t*>(src);
+            if constexpr (TCN) {
+                const unsigned short* base = (ks < 32) ? arow : a.A2_16 + m * a.lda;
+                afr[tm][ks] = *reinterpret_cast<const u32x4_t*>(base + (2 * (ks & 31) + kh) * 8);
+            } else {
+                const int k = (2 * ks + kh) * 8;
+                const bool shifted = (AMODE == A_SHIFT) && (ks < KS / 2);
+                const unsigned short* src = shifted ? (s > 0 ? prow + k : prow + (k & 63)) : arow + k;
+                afr[tm][ks] = *reinterpret_cast<const u32x4_t*>(src);
+            }
         }
     }
+    // TCN: byte offset of this lane's residual values (row of h, 4 kh columns in) from the uniform base, and the load itself as
+    // an assembly statement: the compiler counts only the memory operations it knows of, so a load it issued here would be
+    // awaited with a count that ignores the weight copies and stalls on the youngest of them; the wait is written by hand below
+    unsigned roff = 0;
+    constexpr int RD = 4;                        // residual values are requested RD k tiles before their use (RD divides KT: the buffers rotate in step with the k tiles across column tiles)
+    static_assert(KT % RD == 0, "buffer rotation");
+    u32x2_t rbuf[RD];
+#pragma unroll
+    for (int i = 0; i < RD; ++i) rbuf[i] = u32x2_t{0u, 0u};
+    if constexpr (TCN) {
+        const int s = min(s0 + wr * 32 + l31, S - 1);
+        roff = (unsigned)((((long)b * S + s) * a.lda + 4 * kh) * 2);
+    }
+    auto res_load = [&](u32x2_t& dst, int col) __attribute__((always_inline)) {      // columns col .. col + 3 (+ 4 kh) of the lane's row of h
+        const unsigned short* base = a.A16 + col;
+#ifndef MSF2_DIAG_TCN_NORES
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(roff), "s"(base) : "memory");
+#endif
+    };
     __syncthreads();                                       // bias in LDS; nothing of the ring is in flight yet
 
     // ---- the weight stream ----
@@ -139,10 +180,11 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     unsigned off[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        const int row = (wave * D + i) * 8 + (lane >> 3);
-        off[i] = (unsigned)((row * K + (((lane & 7) ^ bf_swz128(row)) * 8)) * 2);
+        const int row = (wave * D + i) * 8 + (lane >> 3);          // row of the stage; TCN: rows 0-63 are Wg's, 64-127 Wo's
+        off[i] = (unsigned)((((TCN ? row & 63 : row) * K) + (((lane & 7) ^ bf_swz128(row)) * 8)) * 2);
     }
-    const unsigned short* wnext = reinterpret_cast<const unsigned short*>(a.W);     // source of the next stage: column tile, k tile
+    const unsigned short* wbase = reinterpret_cast<const unsigned short*>((TCN && wave >= 2) ? a.W2 : a.W);
+    const unsigned short* wnext = wbase;                    // source of the next stage: column tile, k tile
     const unsigned ring = __builtin_amdgcn_readfirstlane(lds_addr_of(sm));
     auto copy_piece = [&](int slot, int i) __attribute__((always_inline)) {
         dma16_so(wnext, off[i], ring + slot * STAGE + (wave * D + i) * 1024);
@@ -151,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
 #pragma unroll
         for (int i = 0; i < D; ++i) copy_piece(slot, i);
     };
-    const long tile_step = (long)128 * K - (KT - 1) * 64;   // from the last k tile of a column tile to the first of the next
+    const long tile_step = (long)CW * K - (KT - 1) * 64;    // from the last k tile of a column tile to the first of the next
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) {                    // stages 0 .. 2 = k tiles 0 .. 2 of column tile 0, and piece 0 of stage 3
         copy_stage(t);
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     // (both vectors of the folded norm; the plain epilogue has only the bias)
     auto load_vecs = [&](int par, int q, int g0, int nb) __attribute__((always_inline)) {
         load_bias(bq[par], q, g0, nb);
-        if constexpr (NORM) {
+        if constexpr (NORM || TCN) {
             const float* p = sbias + MAXN / 2 + nb + wc * (32 * TNW) + (q % TNW) * 32 + 4 * kh;
             bq2[par][0] = *reinterpret_cast<const float4*>(p + 8 * g0);
             if (GPK == 2) bq2[par][1] = *reinterpret_cast<const float4*>(p + 8 * (g0 + 1));
@@ -213,6 +255,9 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     // the MFMA statements, and the arithmetic hangs on their operands (the optimiser otherwise gathers all of a k tile's
     // arithmetic behind its last MFMA, where nothing hides it).
     float ex[4] = {0.f, 0.f, 0.f, 0.f};
+    float ov[4] = {0.f, 0.f, 0.f, 0.f};       // TCN: the normalised product of the group
+    bool res_in_loop = true;                  // TCN: the residual loads are pipelined with the weight copies (false: requested and awaited in place)
+    int res_col = 0, res_next = 0;            // TCN: first column of the tile being finished / of the one after it
     bool gate_prev = true;         // MERGED: whether the tile being finished is a gate tile (wave-uniform)
     // MERGED: from a row of the first output to the same row of the second, less the second's column offset in the walk (wave-uniform)
     const long out_delta = MERGED ? (reinterpret_cast<char*>(a.out16b) - reinterpret_cast<char*>(a.out16)) - (long)a.N * 2 : 0;
@@ -221,7 +266,70 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         constexpr bool SIG = (ACT == 1 || ACT == 2 || MERGED);
         // K = 512: two groups per k tile (slots 0-7, 8-15); K = 1024: one (slots 0-7; slots 8-15 stay empty)
         const int q = kt / KPQ, tm = q / TNW, tn = q % TNW;
-        const int gi = m >> 3, g = (kt % KPQ) * GPK + gi, ph = m & 7;
+        const int gi = TCN ? 0 : m >> 3, g = (kt % KPQ) * GPK + gi, ph = m & 7;
+        if constexpr (TCN) {
+            // one group per k tile over 16 slots: gate tile q, product tile 2 + q of the previous column tile (res_col = its first column)
+            if (m == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = acc[PP][0][q][4 * g + e] + f4get(bq[kt & 1][0], e);
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+            } else if (m == 1) {
+                asm volatile("" : "+v"(r0[0]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = r0[0] * acc[PP][0][2 + q][4 * g + e] + f4get(bq2[kt & 1][0], e);
+                asm volatile("" : "+v"(ov[0]), "+v"(ov[1]), "+v"(ov[2]), "+v"(ov[3]));
+            } else if (m == 2) {
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ex[e] = val[e] * -1.44269504f;
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+            } else if (m == 3 || m == 4) {
+                const int e0 = (m - 3) * 2;
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+                ex[e0] = __builtin_amdgcn_exp2f(ex[e0]);
+                ex[e0 + 1] = __builtin_amdgcn_exp2f(ex[e0 + 1]);
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+            } else if (m == 5) {
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ex[e] = 1.0f + ex[e];
+                asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+            } else if (m == 6 || m == 7) {
+                const int e0 = (m - 6) * 2;
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+                ex[e0] = __builtin_amdgcn_rcpf(ex[e0]);
+                ex[e0 + 1] = __builtin_amdgcn_rcpf(ex[e0 + 1]);
+                asm volatile("" : "+v"(ex[e0]), "+v"(ex[e0 + 1]));
+            } else if (m == 8) {
+                // the residual requested in slot 13 RD k tiles ago: since then one weight piece, then four pieces and a residual load
+                // per k tile, then two pieces were issued
+#ifndef MSF2_DIAG_TCN_NORES
+                if (res_in_loop) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * RD - 2) : "memory");
+#endif
+                u32x2_t& rb = rbuf[kt % RD];
+                asm volatile("" : "+v"(rb));
+                val[0] = __builtin_bit_cast(float, rb.x << 16); val[1] = __builtin_bit_cast(float, rb.x & 0xffff0000u);
+                val[2] = __builtin_bit_cast(float, rb.y << 16); val[3] = __builtin_bit_cast(float, rb.y & 0xffff0000u);
+#ifdef MSF2_DIAG_TCN_NORES
+                val[0] = val[1] = val[2] = val[3] = 0.f;
+#endif
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+            } else if (m == 9) {
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = val[e] + ex[e] * ov[e];
+                asm volatile("" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
+            } else if (m == 10) {
+                pk[g].x = pk_bf16_2(val[0], val[1]);
+                pk[g].y = pk_bf16_2(val[2], val[3]);
+                asm volatile("" : "+v"(pk[g].x), "+v"(pk[g].y));
+            } else if (m == 13 && res_in_loop) {
+                // the residual of the group RD k tiles on: of this column tile, or of the first groups of the one after it
+                if (kt + RD < KT) res_load(rbuf[kt % RD], res_col + ((kt + RD) / KPQ) * 32 + 8 * ((kt + RD) % KPQ));
+                else res_load(rbuf[kt % RD], res_next + ((kt + RD - KT) / KPQ) * 32 + 8 * ((kt + RD - KT) % KPQ));
+            }
+            return;
+        }
         if (gi >= GPK) return;
         if (ph == 0) {
             asm volatile("" : "+v"(r0[tm]));
@@ -309,7 +417,8 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
     u32x4_t fb[2][TNW];            // weight fragments of two consecutive MFMA steps (ping-pong: step parity)
     auto column_tile = [&](auto par_tag, int ct, bool counted) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
-        const int nprev = (ct - 1) * 128;
+        const int nprev = (ct - 1) * CW;
+        if constexpr (TCN) { res_col = ct > 0 ? nprev : 0; res_next = ct * CW; }      // (the first column tile finishes nothing: any valid column)
         // (the source pointer moves on after piece 3 of a stage; the stage in flight when k tile 4 starts is the last k tile
         // of this column tile, so the pointer then steps to the next column tile -- or wraps)
         const bool wrap_prev = ct == NT - 1;
@@ -345,8 +454,9 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                             else mfma_astat<1>(acc[PAR][TMW - 1][j & 1], fb[sub & 1][j & 1], afr[TMW - 1][kt * 4 + sub]);
                         }
                     } else {
-                        if (kt == 0 && sub == 0) mfma_astat_first<0>(acc[PAR][0][j % TNW], fb[0][j % TNW], afr[0][0]);
-                        else mfma_astat<0>(acc[PAR][0][j % TNW], fb[sub & 1][j % TNW], afr[0][kt * 4 + sub]);
+                        const int fo = (TCN && j >= 2) ? 32 : 0;      // TCN: tiles 2, 3 are the product of t (fragments 32 .. 63)
+                        if (kt == 0 && sub == 0) mfma_astat_first<0>(acc[PAR][0][j % TNW], fb[0][j % TNW], afr[0][fo]);
+                        else mfma_astat<0>(acc[PAR][0][j % TNW], fb[sub & 1][j % TNW], afr[0][fo + kt * 4 + sub]);
                     }
                     if (j < TNW) {
                         if (sub < 3) read_b1(kt & 3, sub + 1, j, fb[(sub + 1) & 1][j]);
@@ -359,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
 #endif
                         if (sub == 2) {
                             if (kt == KT - NST) {
-                                if (wrap_prev) wnext = reinterpret_cast<const unsigned short*>(a.W);
+                                if (wrap_prev) wnext = wbase;
                                 else if (MERGED && ct == NT1 - 1) wnext = reinterpret_cast<const unsigned short*>(a.W2);     // the second projection's weights
                                 else wnext += tile_step;
                             }
@@ -368,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
                     } else if (j == 3 && sub == 3) {
                         // bias of the group(s) the NEXT k tile finishes (the next column tile's first, after the last k tile)
                         if (kt < KT - 1) load_vecs((kt + 1) & 1, (kt + 1) / KPQ, ((kt + 1) % KPQ) * GPK, nprev);
-                        else load_vecs(0, 0, 0, nprev + 128);
+                        else load_vecs(0, 0, 0, nprev + CW);
                     }
 #ifndef MSF2_DIAG_ASTAT_NOEPI
                     epi_slot(par_tag, kt, sub * 4 + j);
@@ -402,12 +512,14 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         if (ct + 1 < NT) column_tile(P1(), ct + 1, interior && ct + 1 >= 2);
     }
     // the last column tile is finished with nothing to hide behind (same slots, no MFMAs between them)
-    const int nlast = (NT - 1) * 128;
+    const int nlast = (NT - 1) * CW;
     if constexpr (MERGED) gate_prev = false;
+    if constexpr (TCN) { res_in_loop = false; res_col = nlast; }
     if (NT & 1) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             load_vecs(kt & 1, kt / KPQ, (kt % KPQ) * GPK, nlast);
+            if constexpr (TCN) { if (kt >= RD) { res_load(rbuf[kt % RD], nlast + (kt / KPQ) * 32 + 8 * (kt % KPQ)); } asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P1(), kt, m);    // (the tag names the set that would FOLLOW: the slot reads set 0)
             if (kt % KPQ == KPQ - 1) store_tile(kt / KPQ, nlast);
@@ -416,6 +528,7 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             load_vecs(kt & 1, kt / KPQ, (kt % KPQ) * GPK, nlast);
+            if constexpr (TCN) { if (kt >= RD) { res_load(rbuf[kt % RD], nlast + (kt / KPQ) * 32 + 8 * (kt % KPQ)); } asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #pragma unroll
             for (int m = 0; m < 16; ++m) epi_slot(P0(), kt, m);
             if (kt % KPQ == KPQ - 1) store_tile(kt / KPQ, nlast);

@@ -508,7 +508,8 @@ def test_bf16_key_value_summary_kernels_agree(B, T):
 
 def test_bf16_equivalent_kernel_forms_on_ragged_shapes():
     """The bit-identical kernel pairs of the bf16 mode (register-resident-activation projections, K = 512 and K = 1024, vs
-    tile kernels; the gate and proj_in of the gated TCN block in one walk vs two; key/value summary global -> LDS kernel vs tile kernel) on a dozen seeded shapes with odd lengths: frame counts just below, at and
+    tile kernels; the gate and proj_in of the gated TCN block in one walk vs two; the two-product TCN contraction with h and t
+    resident in registers vs the tile kernel; key/value summary global -> LDS kernel vs tile kernel) on a dozen seeded shapes with odd lengths: frame counts just below, at and
     just above multiples of the 32-frame k tile, the 128-row tile and the 256-frame group, batches 1 .. 9."""
     cfg2 = type(FULL_8K)(num_layers=2)
     m = MossFormerHIP(cfg2, compute_device=DEV, precision=BF)
@@ -520,7 +521,7 @@ def test_bf16_equivalent_kernel_forms_on_ragged_shapes():
     shapes += [(int(rng.integers(1, 10)), int(rng.integers(1600, 40000))) for _ in range(4)]
     for B, T in shapes:
         x = torch.from_numpy(synth_batch(B, T, seed0=13)).to(DEV)
-        for knob in (b"astat", b"astat_k1024", b"astat_merge", b"linkv_dma"):
+        for knob in (b"astat", b"astat_k1024", b"astat_merge", b"astat_tcn", b"linkv_dma"):
             outs = {}
             for val in (b"1", b"0"):
                 _lib.check(lib.msf2_debug_kernel_choice(None, None))

@@ -28,9 +28,9 @@ for key, sub, fdir, wdir, cmd, note in (
         ("fp32_b16_t32000", "gemm_kernel<msf2::ProjNT<0, 5>", "pmc_fp32_fetch", "pmc_fp32_write",
          "python3 tools/probe_op.py tcn_pointwise --reps 5",
          "gfx950 FETCH_SIZE tallies 128-B requests at 64 B: bytes read = 2 x FETCH_SIZE; WRITE_SIZE exact"),
-        ("bf16_b64_t32000", "gemm_kernel_bf16_dma<msf2::ProjNT<0, 5>", "pmc_bf16_fetch", "pmc_bf16_write",
+        ("bf16_b64_t32000", "proj_astat_bf16_kernel<0, 64", "pmc_bf16_fetch", "pmc_bf16_write",
          "python3 tools/time_tcn16.py",
-         "gfx950 FETCH_SIZE doubled as for wide streaming reads (the copies are whole 128-byte lines per row piece)")):
+         "gfx950 FETCH_SIZE doubled as for wide streaming reads (activation rows as 32-byte segments that add up to whole lines, weights as whole lines)")):
     kn, f, nf = mean_counter(fdir, "FETCH_SIZE", sub)
     _, w, nw = mean_counter(wdir, "WRITE_SIZE", sub)
     out[key] = {"kernel": kn.split("(")[0].replace("void ", "").replace("msf2::", ""),
