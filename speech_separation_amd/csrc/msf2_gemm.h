@@ -144,6 +144,13 @@ __device__ unsigned long long g_stamp2[2048 * 4 * 2];
 #define MSF2_STAMP(x)
 #endif
 
+// Problems whose row tile may reach past the end of their rows say how many of its rows exist (valid_rows()); a wave then
+// skips the fragment reads and MFMAs of its 32-row sub-tiles that hold no row at all (their outputs are never stored) and
+// leaves the matrix pipe of its SIMD to the other workgroup of the CU.
+template <class P, class = void> struct HasValidRows { static constexpr bool value = false; };
+template <class P> struct HasValidRows<P, decltype((void)static_cast<const P*>(nullptr)->valid_rows())> { static constexpr bool value = true; };
+template <int V> struct IntC { static constexpr int value = V; };
+
 template <class P, int SEG, int TM, int TN, int BNT = BN>
 __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* smB,
                                             f32x16 (&acc)[TM][TN], int tid, int lane, int wave, int wr, int wc) {
@@ -180,26 +187,29 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
     land(0);
     const int kh = lane >> 5, l31 = lane & 31;
     const int rowA = wr * (TM * 32) + l31, rowB = wc * (TN * 32) + l31;
-    auto compute = [&](int cur) {
+    // NTM: the 32-row sub-tiles of this wave that hold rows (TM everywhere but at the ragged end)
+    auto compute = [&](int cur, auto ntm_c) {
+        constexpr int NTM = decltype(ntm_c)::value;
+        if constexpr (NTM == 0) return;
         const float* sa = smA + cur * SZA;
         const float* sb = smB + cur * SZB;
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) af[0][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, 0, kh);
+        for (int t = 0; t < NTM; ++t) af[0][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, 0, kh);
 #pragma unroll
         for (int t = 0; t < TN; ++t) bf[0][t] = frag_read<P::B_ORI>(sb, rowB + t * 32, 0, kh);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             if (c + 1 < BK / 8) {     // fragments of chunk c+1 are read while the MFMAs of chunk c issue
 #pragma unroll
-                for (int t = 0; t < TM; ++t) af[(c + 1) & 1][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, c + 1, kh);
+                for (int t = 0; t < NTM; ++t) af[(c + 1) & 1][t] = frag_read<P::A_ORI>(sa, rowA + t * 32, c + 1, kh);
 #pragma unroll
                 for (int t = 0; t < TN; ++t) bf[(c + 1) & 1][t] = frag_read<P::B_ORI>(sb, rowB + t * 32, c + 1, kh);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = P::ACC_T
@@ -207,6 +217,7 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
                             : __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(af[c & 1][tm], j), f4get(bf[c & 1][tn], j), acc[tm][tn], 0, 0, 0);
         }
     };
+    auto main_loop = [&](auto ntm_c) {
     // steady state is branch-free (a conditional around the staging makes hipcc merge
     // register assignments with moves that wait on the loads); the last tile is peeled
 #ifdef MSF2_DIAG_STAMP
@@ -221,7 +232,7 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
         stage(kt + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs that hide their latency
         MSF2_STAMP(s1_)
-        compute(cur);
+        compute(cur, ntm_c);
         __builtin_amdgcn_sched_barrier(0);
         MSF2_STAMP(s2_)
         land(cur ^ 1);
@@ -239,7 +250,14 @@ __device__ __forceinline__ void run_segment(const P& prob, float* smA, float* sm
         }
     }
 #endif
-    compute((nk - 1) & 1);
+    compute((nk - 1) & 1, ntm_c);
+    };
+    int ntm = TM;
+    if constexpr (HasValidRows<P>::value) ntm = min(max((prob.valid_rows() - wr * (TM * 32) + 31) >> 5, 0), TM);      // (wave-uniform)
+    if (ntm >= TM || ntm > 2) main_loop(IntC<TM>{});
+    else if (ntm == 2) main_loop(IntC<(TM > 2 ? 2 : TM)>{});
+    else if (ntm == 1) main_loop(IntC<1>{});
+    else main_loop(IntC<0>{});
     __syncthreads();
 }
 
@@ -445,6 +463,7 @@ struct ProjNT {
         return min(a.ncol_loop > 1 ? a.ncol_loop : 1, left);
     }
     __device__ int nk(int) const { return a.K / BK; }
+    __device__ int valid_rows() const { return a.S - s0; }      // rows of this tile that exist
     // rows past the end of the utterance are clamped (their outputs are never stored)
     __device__ const float* ptrA(int seg, int kt, int r, int ko) const {
         const int s = min(s0 + r, a.S - 1);
