@@ -137,13 +137,21 @@ __global__ __launch_bounds__(256, 1) void proj_astat_bf16_kernel(const ProjArgs 
         else if constexpr (TCN) r0[tm] = a.bstat[2 * b + 1];          // rstd of the utterance (the mean is folded into c1f)
         else r0[tm] = a.rowstat ? a.rowstat[m] : 1.f;
         orow[tm] = reinterpret_cast<char*>(a.out16) + (m * a.ldo + wc * (32 * TNW)) * 2 + kh * 16;
+#ifdef MSF2_DIAG_ASTAT_NOFRAG
+        const unsigned short* arow = a.A16 + (m & 31) * a.lda;      // timing-only build: every workgroup's fragments from the same (cache-resident) rows
+#else
         const unsigned short* arow = a.A16 + m * a.lda;
+#endif
         // token shift: the first half of the features comes from the previous frame, zeros at frame 0
         const unsigned short* prow = (AMODE == A_SHIFT) ? (s > 0 ? arow - a.lda : reinterpret_cast<const unsigned short*>(a.zeros)) : arow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (TCN) {
+#ifdef MSF2_DIAG_ASTAT_NOFRAG
+                const unsigned short* base = arow;
+#else
                 const unsigned short* base = (ks < 32) ? arow : a.A2_16 + m * a.lda;
+#endif
                 afr[tm][ks] = *reinterpret_cast<const u32x4_t*>(base + (2 * (ks & 31) + kh) * 8);
             } else {
                 const int k = (2 * ks + kh) * 8;
